@@ -1,0 +1,140 @@
+/* libvista_hip.so -- C ABI of the MI355X (gfx950) kernels behind the Vista denoising hot path.
+ *
+ * Contract: every entry point borrows device pointers, enqueues on the given HIP stream, performs
+ * no allocation and no synchronisation, and returns 0 or a negative errno-style code (-22 bad argument, -5 launch
+ * failure). The reference has no FFI of its own (it is pure Python); each function below names the reference
+ * call site (file:line under the Vista tree) whose third-party ATen / xformers arithmetic it replaces. The Python
+ * boundary classes in vista_amd/modules mirror the reference classes and are the only callers.
+ *
+ * Activation layout everywhere: token-major "NHWC" bf16, tensor[(b*T + t)][y*W + x][c], c contiguous.
+ * bf16 is passed as uint16_t bit patterns. "stream" is a hipStream_t passed as void*.
+ */
+#ifndef VISTA_HIP_H
+#define VISTA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ GEMM / implicit-GEMM convolution */
+enum { VK_AMODE_DENSE = 0, VK_AMODE_CONV3X3 = 1, VK_AMODE_TEMPORAL3 = 2 };
+enum { VK_EPI_LINEAR = 0, VK_EPI_GEGLU = 1, VK_EPI_TRANS = 2 };
+
+typedef struct VkGemmDesc {
+    const void* A;       /* bf16 activations: [M][lda] (DENSE) or NHWC source image stack (conv modes)            */
+    const void* Wt;      /* bf16 weights [ceil128(N)][K], K contiguous; conv: [Cout][tap][Cin]                    */
+    void* out;           /* bf16 or f32 [M][ldc]; EPI_TRANS: bf16 [M/S][N][S]                                     */
+    const float* bias;   /* [ceil128(N)] f32 or NULL (EPI_GEGLU: in packed row order)                             */
+    const float* rowvec; /* f32 [M/rows_per_vec][ldv] added per image, or NULL                                    */
+    const void* res1;    /* bf16 [M][ld_res1] residual added before alpha, or NULL                                */
+    const void* res2;    /* bf16 [M][ld_res2] residual added with beta, or NULL                                   */
+    int32_t M, N, K;
+    int32_t lda, ldc, ld_res1, ld_res2, ldv, rows_per_vec;
+    float alpha, beta;   /* out = alpha*(acc + bias + rowvec + res1) + beta*res2                                  */
+    int32_t amode, epi, out_f32;
+    int32_t H, Wd, Cin, Hout, Wout, stride, ups; /* CONV3X3: source H x Wd (before the x`ups` nearest upsample)   */
+    int32_t T, S;        /* TEMPORAL3: frames per clip, tokens per frame. EPI_TRANS: S = tokens per image         */
+} VkGemmDesc;
+
+/* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
+ *   vwm/modules/attention.py:85-92,117-121 (GEGLU FF), :344-346,421 (q,k,v,out), :579,602 (proj_in/out)
+ *   vwm/modules/diffusionmodules/openaimodel.py:136 (Downsample), :84,100-102 (Upsample), :195-199,227-234 (ResBlock convs), :241 (skip)
+ *   vwm/modules/diffusionmodules/video_model.py:38-52 (3x1x1 temporal conv), :148-157,176-182 (embedding MLPs), :189,438 (in/out conv) */
+int vk_gemm_bf16(const VkGemmDesc* d, void* stream);
+
+/* ------------------------------------------------------------------ attention */
+/* Spatial self-attention, softmax(q k^T * scale) v per (image, head), head dim 64, no mask.
+ * Replaces xformers.ops.memory_efficient_attention at vwm/modules/attention.py:400-407 for attn1 of
+ * BasicTransformerBlock (attention.py:514-518).
+ *   q, k : bf16, row (image*S + token) at q + row*ldq + head*64 (same for k / ldk)
+ *   vt   : bf16 [n_img][heads][64][S]   (V transposed, produced by vk_gemm_bf16 EPI_TRANS)
+ *   o    : bf16, row at o + row*ldo + head*64
+ * S must be a multiple of 8. */
+int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
+                         int32_t S, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream);
+
+/* Temporal (cross-frame) self-attention over the T frames of every pixel: sequence length T <= 32, head dim 64.
+ * Replaces the batchified xformers call at vwm/modules/attention.py:384-399 for VideoTransformerBlock.attn1
+ * (vwm/modules/video_attention.py:116-127). Token rows are (b*T + t)*S + s; q,k,v are column blocks of one
+ * row-major buffer: q at qkv + row*ld + head*64, k at + k_off, v at + v_off. */
+int vk_attn_temporal_bf16(const void* qkv, void* o, int32_t B, int32_t T, int32_t S, int32_t heads, int32_t ld,
+                          int32_t k_off, int32_t v_off, int32_t ldo, float scale, void* stream);
+
+/* ------------------------------------------------------------------ normalisation */
+/* GroupNorm(32 groups) [+ SiLU] over token-major x[n_img][S][C]; statistics span `frames_per_group` consecutive
+ * images (1 = per-image GroupNorm32 of the 2-D ResBlock / transformer entry norm; T = the 5-D norm of the
+ * temporal ResBlock whose statistics cover (C/32, T, H, W)).
+ * Replaces GroupNorm32/Normalize + nn.SiLU: vwm/modules/diffusionmodules/util.py:196-216, attention.py:141-142,
+ * openaimodel.py:195-199,227-230, video_model.py:434-436.
+ * stats_ws: f32 workspace of 2*32*(n_img/frames_per_group) floats (zeroed by the call). */
+int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
+                           int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group, float eps, int32_t silu,
+                           void* stream);
+
+/* LayerNorm over C of x[rows][C] (+ optional per-image pre-add vector):  u = x + addvec[row / rows_per_vec];
+ * if sum_out: sum_out = u (bf16);  y = LN(u)*gamma + beta.
+ * Replaces nn.LayerNorm at attention.py:514-524 (norm1-3) and video_attention.py:119-137 (norm_in, norm1-3),
+ * fused with the `x_mix = x + emb` add of video_attention.py:283-284. */
+int vk_layernorm_bf16(const void* x, void* y, void* sum_out, const float* gamma, const float* beta,
+                      const float* addvec, int32_t rows, int32_t C, int32_t rows_per_vec, int32_t ldv, float eps,
+                      void* stream);
+
+/* ------------------------------------------------------------------ elementwise / layout */
+/* out[m][0:C1] = a[m][:], out[m][C1:C1+C2] = b[m][:]  (channel concat of the UNet skip: video_model.py:493) */
+int vk_concat_channels_bf16(const void* a, const void* b, void* out, int64_t rows, int32_t C1, int32_t C2, void* stream);
+
+/* NCHW float (f32) -> token-major bf16 with the channel dim zero-padded to Cpad (UNet entry; video_model.py:473) */
+int vk_nchw_to_tokens_bf16(const float* x, void* out, int32_t n_img, int32_t C, int32_t HW, int32_t Cpad, void* stream);
+/* token-major f32 [n_img][HW][ldx] (first C columns) -> NCHW f32 (UNet exit; video_model.py:502-503) */
+int vk_tokens_to_nchw_f32(const float* x, float* out, int32_t n_img, int32_t C, int32_t HW, int32_t ldx, void* stream);
+
+/* sinusoidal timestep embedding: out[n][0:half]=cos(t[n]*f_j), out[n][half:]=sin(t[n]*f_j), f_j=exp(-ln(max_period)*j/half)
+ * (vwm/modules/diffusionmodules/util.py:141-165); bf16 output feeds the embedding MLPs */
+int vk_timestep_embedding_bf16(const float* t, void* out, int32_t n, int32_t dim, float max_period, void* stream);
+
+/* emb = a*mask[n] + b*(1-mask[n]) + c  (video_model.py:457-471); writes emb (f32) and silu(emb) (bf16, the input
+ * of every ResBlock emb_layers: openaimodel.py:222-225). a may be NULL (no cond-frame mask: emb = b + c). */
+int vk_emb_combine(const float* a, const float* b, const float* c, const float* mask, float* emb, void* silu_out,
+                   int32_t n, int32_t dim, void* stream);
+
+/* y = silu(x) f32 -> bf16 (time_pos_embed MLP hidden: video_attention.py:227-231) */
+int vk_silu_f32_to_bf16(const float* x, void* y, int64_t count, void* stream);
+/* y = bf16(x) */
+int vk_cast_f32_to_bf16(const float* x, void* y, int64_t count, void* stream);
+
+/* ---- sampler-side fused elementwise (EulerEDMSampler step; sampling.py:78-89,104-122, guiders.py:23-36,
+ *      denoiser.py:30-35, denoiser_scaling.py:51-59, wrappers.py:28-31) ----
+ * x, cond_frame: f32 NCHW [T][4][HW]; mask: f32 [T].
+ * vk_sampler_prepare: xr = x*(1-mask) + cond_frame*mask (written back to x when replace != 0) and builds the
+ *   CFG-doubled UNet input in token-major bf16 [2T][HW][Cpad]: ch 0-3 = xr * c_in, ch 4-7 = concat latent
+ *   (uncond half: concat_uc, cond half: concat_c; f32 NCHW [T][4][HW]), remaining channels 0. */
+int vk_sampler_prepare(float* x, const float* cond_frame, const float* mask, const float* concat_uc,
+                       const float* concat_c, void* net_in, int32_t T, int32_t HW, int32_t Cpad, float c_in,
+                       int32_t replace, void* stream);
+/* vk_sampler_update: net_out f32 token-major [2T][HW][ld] (first 4 cols). den = net*c_out + x*c_skip for both
+ *   halves; g = den_u + scale[t]*(den_c - den_u); d = (x - g)/sigma; x += d*(sigma_next - sigma). */
+int vk_sampler_update(float* x, const float* net_out, const float* scale, int32_t T, int32_t HW, int32_t ld,
+                      float c_out, float c_skip, float sigma, float sigma_next, void* stream);
+
+/* generic pieces of the same maths for callers that use the reference's Denoiser / guider API directly */
+/* out = net*c_out[n] + x*c_skip[n]  (NCHW f32, per-image coefficients; denoiser.py:35) */
+int vk_denoiser_combine(const float* net, const float* x, const float* c_out, const float* c_skip, float* out,
+                        int32_t n_img, int32_t chw, void* stream);
+/* out[t] = u[t] + scale[t]*(c[t]-u[t]) with u = x[0:T], c = x[T:2T]  (guiders.py:23-26,54-61) */
+int vk_cfg_combine(const float* x2, const float* scale, float* out, int32_t T, int32_t chw, void* stream);
+/* x_next = x + (x - den)/sigma[n] * (sigma_next[n]-sigma[n])  (sampling_utils.py:46-47; sampling.py:66-67,85-88) */
+int vk_euler_step(const float* x, const float* den, const float* sigma, const float* sigma_next, float* out,
+                  int32_t n_img, int32_t chw, void* stream);
+/* out = x*(1-mask[n]) + cond*mask[n]  (sampling.py:106,122) */
+int vk_mask_replace(const float* x, const float* cond, const float* mask, float* out, int32_t n_img, int32_t chw,
+                    void* stream);
+/* out = x * s[n]  (per-image scale, NCHW f32; denoiser.py:35 `noised_input * c_in`) */
+int vk_scale_rows(const float* x, const float* s, float* out, int32_t n_img, int32_t chw, void* stream);
+
+/* library info */
+int vk_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,339 @@
+"""Per-kernel numerics of libvista_hip.so against plain PyTorch fp32 references of the same op (run on the GPU box).
+
+Inputs are bf16-representable, the reference is computed in fp32 from those same values, so the only error left is
+the kernel's bf16 output rounding + fp32 accumulation order.  Tolerance (stated): |out - ref| <= 2e-2*rms(ref) + 1.6e-2*|ref|
+(bf16 has 8 bits of mantissa: 2^-8 = 3.9e-3 relative per rounding; attention adds the bf16 rounding of P).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _ops():
+    from vista_amd import ops
+    return ops
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(BF16).cuda()
+
+
+def close(out, ref, name, rtol=1.6e-2, arel=2e-2):
+    out = out.float()
+    ref = ref.float()
+    assert out.shape == ref.shape, f"{name}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    rms = ref.pow(2).mean().sqrt().item()
+    err = (out - ref).abs()
+    tol = arel * rms + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(
+            f"{name}: {int(bad.sum())}/{bad.numel()} out of tolerance; max err {err.max().item():.4g} (rms ref {rms:.4g}); "
+            f"first bad idx {idx}: out {out[tuple(idx)].item():.5g} ref {ref[tuple(idx)].item():.5g}")
+    return err.max().item() / (rms + 1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (50, 1280, 768), (128, 128, 64), (1000, 4, 576), (257, 960, 2432), (4608, 640, 1280)])
+def test_linear_plain(M, N, K):
+    ops = _ops()
+    x = rnd(M, K)
+    w = rnd(N, K, scale=K ** -0.5, seed=1)
+    b = rnd(N, seed=2).float()
+    pw = ops.pack_linear(w, b)
+    out = ops.linear(x, pw)
+    ref = x.float() @ w.float().t() + b
+    close(out, ref, f"linear {M}x{N}x{K}")
+    out32 = ops.linear(x, pw, out_f32=True)
+    assert out32.dtype == F32
+    close(out32, ref, f"linear f32 {M}x{N}x{K}", rtol=2e-3, arel=2e-3)
+
+
+def test_linear_asymmetric_identity():
+    """A = I against an asymmetric W catches a transposed accumulator layout (symmetric data would not)."""
+    ops = _ops()
+    K = 128
+    x = torch.eye(K, dtype=BF16, device="cuda")
+    w = (torch.arange(256 * K, dtype=F32).reshape(256, K) % 251 - 125).div(64).to(BF16).cuda()
+    out = ops.linear(x, ops.pack_linear(w, None), out_f32=True)
+    assert torch.equal(out, w.float().t().contiguous()), "identity GEMM must reproduce W^T exactly"
+
+
+def test_linear_epilogue_full():
+    ops = _ops()
+    M, N, K, rpv = 600, 320, 640, 100
+    x = rnd(M, K)
+    w = rnd(N, K, scale=K ** -0.5, seed=1)
+    b = rnd(N, seed=2).float()
+    rv = rnd(M // rpv, N, seed=3).float()
+    r1 = rnd(M, N, seed=4)
+    r2 = rnd(M, N, seed=5)
+    out = ops.linear(x, ops.pack_linear(w, b), rowvec=rv, rows_per_vec=rpv, res1=r1, res2=r2, alpha=0.3, beta=0.7)
+    ref = 0.3 * (x.float() @ w.float().t() + b + rv.repeat_interleave(rpv, 0) + r1.float()) + 0.7 * r2.float()
+    close(out, ref, "linear full epilogue")
+
+
+def test_linear_strided_views():
+    ops = _ops()
+    M, N, K = 260, 320, 320
+    big = rnd(M, 3 * K)
+    x = big[:, K:2 * K]
+    w = rnd(N, K, scale=K ** -0.5, seed=1)
+    outbuf = torch.zeros(M, 2 * N, dtype=BF16, device="cuda")
+    ops.linear(x, ops.pack_linear(w, None), out=outbuf[:, N:])
+    close(outbuf[:, N:], x.float() @ w.float().t(), "linear strided")
+    assert outbuf[:, :N].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("M,C", [(200, 64), (460, 320), (130, 1280)])
+def test_geglu(M, C):
+    ops = _ops()
+    x = rnd(M, C)
+    w = rnd(8 * C, C, scale=C ** -0.5, seed=1)
+    b = rnd(8 * C, seed=2).float()
+    out = ops.linear(x, ops.pack_geglu(w, b))
+    h = x.float() @ w.float().t() + b
+    a, g = h.chunk(2, dim=-1)
+    close(out, a * F.gelu(g), f"geglu {M}x{C}")
+
+
+@pytest.mark.parametrize("n_img,S,C", [(3, 144, 320), (2, 576, 640), (5, 16, 64)])
+def test_linear_vt(n_img, S, C):
+    ops = _ops()
+    x = rnd(n_img * S, C)
+    w = rnd(C, C, scale=C ** -0.5, seed=1)
+    vt = ops.linear_vt(x, ops.pack_linear(w, None), S)
+    ref = (x.float() @ w.float().t()).view(n_img, S, C).transpose(1, 2)
+    close(vt, ref, "linear_vt")
+
+
+def _tok2nchw(x, n, H, W):
+    return x.float().view(n, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def _nchw2tok(x):
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n, h * w, c)
+
+
+@pytest.mark.parametrize("n,H,W,Cin,Cout,stride,ups", [
+    (2, 9, 16, 64, 320, 1, 1), (3, 18, 32, 320, 320, 1, 1), (2, 18, 32, 128, 64, 2, 1), (2, 9, 16, 192, 128, 1, 2),
+    (1, 72, 128, 64, 4, 1, 1), (2, 7, 5, 64, 64, 1, 1), (2, 8, 6, 64, 64, 2, 1)])
+def test_conv3x3(n, H, W, Cin, Cout, stride, ups):
+    ops = _ops()
+    x = rnd(n, H * W, Cin)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1)
+    b = rnd(Cout, seed=2).float()
+    out, Ho, Wo = ops.conv3x3(x, ops.pack_conv3x3(w, b), n, H, W, stride=stride, ups=ups)
+    xi = _tok2nchw(x, n, H, W)
+    if ups == 2:
+        xi = F.interpolate(xi, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xi, w.float(), b, stride=stride, padding=1)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    close(out, _nchw2tok(ref), f"conv3x3 s{stride} u{ups}")
+
+
+def test_conv3x3_epilogue_rowvec_res():
+    ops = _ops()
+    n, H, W, Cin, Cout = 4, 9, 16, 128, 192
+    x = rnd(n, H * W, Cin)
+    w = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1)
+    b = rnd(Cout, seed=2).float()
+    rv = rnd(n, Cout, seed=3).float()
+    r1 = rnd(n, H * W, Cout, seed=4)
+    out, _, _ = ops.conv3x3(x, ops.pack_conv3x3(w, b), n, H, W, rowvec=rv, res1=r1)
+    ref = _nchw2tok(F.conv2d(_tok2nchw(x, n, H, W), w.float(), b, padding=1)) + rv[:, None, :] + r1.float()
+    close(out, ref, "conv3x3 epilogue")
+
+
+def test_conv_in_pad8():
+    """UNet input conv: 8 real channels zero-padded to 64 (video_model.py:189)."""
+    ops = _ops()
+    n, H, W = 2, 9, 16
+    x8 = rnd(n, 8, H, W).float()
+    w = rnd(320, 8, 3, 3, scale=72 ** -0.5, seed=1)
+    b = rnd(320, seed=2).float()
+    xt = ops.nchw_to_tokens(x8, 64)
+    out, _, _ = ops.conv3x3(xt, ops.pack_conv3x3(w, b, cin_pad=64), n, H, W)
+    close(out, _nchw2tok(F.conv2d(x8, w.float(), b, padding=1)), "in conv")
+
+
+@pytest.mark.parametrize("B,T,S,C", [(2, 25, 24, 64), (1, 25, 144, 320), (2, 5, 16, 128)])
+def test_conv_t3(B, T, S, C):
+    ops = _ops()
+    x = rnd(B * T, S, C)
+    w = rnd(C, C, 3, 1, 1, scale=(3 * C) ** -0.5, seed=1)
+    b = rnd(C, seed=2).float()
+    rv = rnd(B * T, C, seed=3).float()
+    res = rnd(B * T, S, C, seed=4)
+    out = ops.conv_t3(x, ops.pack_conv_t3(w, b), T, S, rowvec=rv, res2=res, alpha=0.4, beta=1.0)
+    x5 = x.float().view(B, T, S, 1, C).permute(0, 4, 1, 2, 3)  # b c t s 1
+    ref5 = F.conv3d(x5, w.float(), b, padding=(1, 0, 0))
+    ref = ref5.permute(0, 2, 3, 4, 1).reshape(B * T, S, C)
+    ref = 0.4 * (ref + rv[:, None, :]) + res.float()
+    close(out, ref, "conv_t3")
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _sdpa(q, k, v):
+    s = (q.float() @ k.float().transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    return torch.softmax(s, -1) @ v.float()
+
+
+@pytest.mark.parametrize("n_img,heads,S", [(2, 5, 144), (1, 2, 576), (3, 1, 64), (1, 5, 2304), (2, 3, 200), (1, 1, 9216)])
+def test_attn_spatial(n_img, heads, S):
+    ops = _ops()
+    Cc = heads * 64
+    x = rnd(n_img * S, Cc, scale=1.0)
+    wq, wk, wv = (rnd(Cc, Cc, scale=1.5 * Cc ** -0.5, seed=s) for s in (1, 2, 3))
+    qk = ops.linear(x, ops.pack_linear_cat([wq, wk]))
+    vt = ops.linear_vt(x, ops.pack_linear(wv, None), S)
+    o = ops.attn_spatial(qk[:, :Cc], qk[:, Cc:], vt, n_img, heads, S)
+    q = qk[:, :Cc].float().view(n_img, S, heads, 64).permute(0, 2, 1, 3)
+    k = qk[:, Cc:].float().view(n_img, S, heads, 64).permute(0, 2, 1, 3)
+    v = vt.float().view(n_img, heads, 64, S).transpose(-1, -2)
+    ref = _sdpa(q, k, v).permute(0, 2, 1, 3).reshape(n_img * S, Cc)
+    close(o, ref, f"attn_spatial S={S}", rtol=2e-2, arel=3e-2)
+
+
+def test_attn_spatial_spike_forces_rescale():
+    """One key row strongly aligned with one query row so the running max jumps mid-sequence (online-softmax rescale path)."""
+    ops = _ops()
+    S, heads = 512, 1
+    q = rnd(S, 64)
+    k = rnd(S, 64, seed=1)
+    v = rnd(S, 64, seed=2)
+    k[300] = q[7] * 4
+    k[450] = q[100] * 6
+    vt = v.t().contiguous().view(1, 64, S)
+    o = ops.attn_spatial(q, k, vt, 1, heads, S)
+    close(o, _sdpa(q[None], k[None], v[None])[0], "attn spike", rtol=2e-2, arel=3e-2)
+
+
+@pytest.mark.parametrize("B,T,S,heads", [(2, 25, 40, 5), (1, 25, 144, 2), (2, 7, 9, 1), (1, 32, 16, 3)])
+def test_attn_temporal(B, T, S, heads):
+    ops = _ops()
+    Cc = heads * 64
+    qkv = rnd(B * T * S, 3 * Cc)
+    o = ops.attn_temporal(qkv, B, T, S, heads)
+    t5 = qkv.float().view(B, T, S, 3, heads, 64)
+    q, k, v = (t5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))  # b s h t d
+    ref = _sdpa(q, k, v).permute(0, 3, 1, 2, 4).reshape(B * T * S, Cc)
+    close(o, ref, "attn_temporal", rtol=2e-2, arel=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("n,S,C,fpg,silu,eps", [(4, 144, 320, 1, True, 1e-5), (6, 100, 64, 1, False, 1e-6), (6, 64, 192, 3, True, 1e-5),
+                                                 (2, 576, 960, 1, True, 1e-5), (50, 16, 2560, 25, True, 1e-5), (2, 300, 1920, 2, False, 1e-5)])
+def test_groupnorm(n, S, C, fpg, silu, eps):
+    ops = _ops()
+    x = (rnd(n, S, C).float() * 1.5 + 0.7).to(BF16)
+    gamma = rnd(C, seed=1).float() + 1.0
+    beta = rnd(C, seed=2).float()
+    y = ops.groupnorm(x, gamma, beta, eps, silu, frames_per_group=fpg)
+    xg = x.float().view(n // fpg, fpg * S, C).permute(0, 2, 1)  # (groups of images, C, fpg*S)
+    ref = F.group_norm(xg, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    close(y, ref.permute(0, 2, 1).reshape(n, S, C), f"groupnorm C={C} fpg={fpg}")
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (300, 64), (257, 640), (129, 1280)])
+def test_layernorm(rows, C):
+    ops = _ops()
+    x = (rnd(rows, C).float() * 2 + 0.3).to(BF16)
+    gamma = rnd(C, seed=1).float() + 1.0
+    beta = rnd(C, seed=2).float()
+    y = ops.layernorm(x, gamma, beta)
+    close(y, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), f"layernorm C={C}")
+    rpv = 50
+    av = rnd((rows + rpv - 1) // rpv, C, seed=3).float()
+    y2, s2 = ops.layernorm(x, gamma, beta, addvec=av, rows_per_vec=rpv, want_sum=True)
+    u = (x.float() + av.repeat_interleave(rpv, 0)[:rows]).to(BF16)
+    assert torch.equal(s2, u), "layernorm sum_out must be the bf16-rounded x + addvec"
+    close(y2, F.layer_norm(u.float(), (C,), gamma, beta, 1e-5), f"layernorm+add C={C}")
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_concat_and_layout():
+    ops = _ops()
+    a, b = rnd(7, 33, 64), rnd(7, 33, 128, seed=1)
+    assert torch.equal(ops.concat_channels(a, b), torch.cat([a, b], -1))
+    x = rnd(3, 8, 9, 16).float()
+    t = ops.nchw_to_tokens(x, 64)
+    assert torch.equal(t[..., :8], x.permute(0, 2, 3, 1).reshape(3, 144, 8).to(BF16))
+    assert t[..., 8:].abs().max().item() == 0
+    y = torch.randn(3, 144, 4, device="cuda")
+    assert torch.equal(ops.tokens_to_nchw(y, 3, 4, 9, 16), y.view(3, 9, 16, 4).permute(0, 3, 1, 2).contiguous())
+
+
+def test_timestep_embedding_and_emb_combine():
+    ops = _ops()
+    t = torch.tensor([0.25 * math.log(700.0), 0.0, -1.553652, 3.0, 24.0], device="cuda")
+    dim = 320
+    e = ops.timestep_embedding(t, dim)
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=F32, device="cuda") / half)
+    args = t[:, None] * freqs[None]
+    ref = torch.cat([torch.cos(args), torch.sin(args)], -1)
+    assert (e.float() - ref).abs().max().item() < 1e-2
+    # KAT from the reference: timestep_embedding(0.25*ln 700, 320)[:3] and [160:163]
+    kat = torch.tensor([-0.06692367, 0.02463922, 0.11090361, 0.99775809, 0.99969643, 0.99383116])
+    got = torch.cat([e[0, :3], e[0, 160:163]]).float().cpu()
+    assert (got - kat).abs().max().item() < 6e-3
+    a, b, c = (torch.randn(5, 64, device="cuda") for _ in range(3))
+    m = torch.tensor([1.0, 0, 0, 1, 0], device="cuda")
+    emb, se = ops.emb_combine(a, b, c, m)
+    ref = a * m[:, None] + b * (1 - m[:, None]) + c
+    assert torch.allclose(emb, ref, atol=1e-6)
+    close(se, F.silu(ref), "silu(emb)")
+    emb2, _ = ops.emb_combine(None, b, c, None)
+    assert torch.allclose(emb2, b + c, atol=1e-6)
+
+
+def test_sampler_elementwise():
+    ops = _ops()
+    T, H, W = 5, 9, 16
+    x = torch.randn(T, 4, H, W, device="cuda") * 10
+    cf = torch.randn(T, 4, H, W, device="cuda")
+    mask = torch.tensor([1.0, 0, 0, 1, 0], device="cuda")
+    cc = torch.randn(T, 4, H, W, device="cuda")
+    c_in = 0.37
+    x0 = x.clone()
+    net_in = ops.sampler_prepare(x, cf, mask, None, cc, 64, c_in, True)
+    xr = x0 * (1 - mask.view(-1, 1, 1, 1)) + cf * mask.view(-1, 1, 1, 1)
+    assert torch.allclose(x, xr, atol=1e-6)
+    tok = lambda z: z.permute(0, 2, 3, 1).reshape(T, H * W, 4)
+    assert torch.equal(net_in[:T, :, :4], tok(xr * c_in).to(BF16))
+    assert torch.equal(net_in[T:, :, :4], tok(xr * c_in).to(BF16))
+    assert net_in[:T, :, 4:].abs().max().item() == 0
+    assert torch.equal(net_in[T:, :, 4:8], tok(cc).to(BF16))
+    assert net_in[T:, :, 8:].abs().max().item() == 0
+    net = torch.randn(2 * T, H * W, 4, device="cuda")
+    scale = torch.linspace(1, 2.5, T, device="cuda")
+    c_out, c_skip, sig, sign = -0.9, 0.2, 3.0, 2.0
+    xb = x.clone()
+    ops.sampler_update(x, net, scale, c_out, c_skip, sig, sign)
+    untok = lambda z: z.view(T, H, W, 4).permute(0, 3, 1, 2)
+    du = untok(net[:T]) * c_out + xb * c_skip
+    dc = untok(net[T:]) * c_out + xb * c_skip
+    g = du + scale.view(-1, 1, 1, 1) * (dc - du)
+    ref = xb + (xb - g) / sig * (sign - sig)
+    assert torch.allclose(x, ref, rtol=1e-5, atol=1e-5)
+    # generic pieces
+    n2 = torch.randn(2 * T, 4, H, W, device="cuda")
+    assert torch.allclose(ops.cfg_combine(n2, scale), n2[:T] + scale.view(-1, 1, 1, 1) * (n2[T:] - n2[:T]), atol=1e-6)
+    sg = torch.full((T,), 3.0, device="cuda"); sn = torch.full((T,), 2.0, device="cuda")
+    assert torch.allclose(ops.euler_step(xb, g, sg, sn), ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(ops.mask_replace(x0, cf, mask), xr, atol=1e-6)
+    co = torch.randn(T, device="cuda"); cs = torch.randn(T, device="cuda")
+    assert torch.allclose(ops.denoiser_combine(xb, cf, co, cs), xb * co.view(-1, 1, 1, 1) + cf * cs.view(-1, 1, 1, 1), atol=1e-5)
+    assert torch.allclose(ops.scale_rows(xb, co), xb * co.view(-1, 1, 1, 1), atol=1e-6)

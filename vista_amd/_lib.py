@@ -1,0 +1,82 @@
+"""ctypes binding of libvista_hip.so (C ABI declared in include/vista_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the HIP library is missing or fails to load, every op
+raises. `load()` is the single place the shared object is opened (in-tree, vista_amd/lib/libvista_hip.so).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvista_hip.so")
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+
+class VkGemmDesc(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("Wt", _vp), ("out", _vp), ("bias", _vp), ("rowvec", _vp), ("res1", _vp), ("res2", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32),
+        ("lda", _i32), ("ldc", _i32), ("ld_res1", _i32), ("ld_res2", _i32), ("ldv", _i32), ("rows_per_vec", _i32),
+        ("alpha", _f32), ("beta", _f32),
+        ("amode", _i32), ("epi", _i32), ("out_f32", _i32),
+        ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32),
+        ("T", _i32), ("S", _i32),
+    ]
+
+
+# name -> argtypes; every entry returns int. Must list every symbol include/vista_hip.h declares
+# (tests/test_abi.py checks the header against this table and against the built library).
+SIGNATURES = {
+    "vk_gemm_bf16": [C.POINTER(VkGemmDesc), _vp],
+    "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_attn_temporal_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_groupnorm_silu_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
+    "vk_layernorm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_concat_channels_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "vk_nchw_to_tokens_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "vk_tokens_to_nchw_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "vk_timestep_embedding_bf16": [_vp, _vp, _i32, _i32, _f32, _vp],
+    "vk_emb_combine": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "vk_silu_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "vk_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "vk_sampler_prepare": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _i32, _vp],
+    "vk_sampler_update": [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp],
+    "vk_denoiser_combine": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "vk_cfg_combine": [_vp, _vp, _vp, _i32, _i32, _vp],
+    "vk_euler_step": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "vk_mask_replace": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
+    "vk_scale_rows": [_vp, _vp, _vp, _i32, _i32, _vp],
+    "vk_abi_version": [],
+}
+
+_lib = None
+
+
+class VistaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Open libvista_hip.so and declare prototypes. Raises VistaHipError when the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VistaHipError(
+            f"{LIB_PATH} not found: build it with `python -m vista_amd.build` (hipcc --offload-arch=gfx950). "
+            "vista_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, surfaced loudly
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise VistaHipError(f"{what} failed with code {rc} (see include/vista_hip.h: -22 bad argument, -5 launch failure)")

@@ -1,0 +1,366 @@
+// Attention cores of the VideoUNet on gfx950 (wave64, MFMA 32x32x16 bf16, fp32 softmax/accumulate).
+//
+// vk_attn_spatial_bf16 -- flash-style spatial self-attention (BasicTransformerBlock.attn1;
+//   vwm/modules/attention.py:370-407,514-518): per (image, head), N = H*W tokens, d = 64, no mask.
+//   Work decomposition: one workgroup = 128 query rows (4 waves x 32 rows) of one (image, head); KV is streamed
+//   in 64-key tiles through a 2-stage LDS ring (K tile [64 keys][64 d], V^T tile [64 d][64 keys], 8 KiB each).
+//   The score MFMA is issued swapped, S^T = K . Q^T, so a lane owns ONE query column and 32 of the tile's keys:
+//   the row max / row sum are lane-local plus a single lane^32 exchange, and the bf16 probabilities are already
+//   in MFMA B-operand position for O^T = V^T . P^T -- the PV contraction simply enumerates the keys in the order
+//   the accumulator holds them (k-slot (half h, i) <-> key 16J + 8*(i>>2) + 4h + (i&3)) and the V^T fragment is
+//   read from LDS in that same order (two ds_read_b64 per fragment). No cross-lane permutes, no P round trip.
+//   V^T ([img][head][64][S]) is produced directly by the value projection GEMM (EPI_TRANS), so both LDS tiles are
+//   filled with plain coalesced 16-B row chunks.
+//   LDS swizzles: K rows are 128 B, 16-B chunk ^= (row>>1)&7 (ds_read_b128 conflict-free); V^T rows are 128 B,
+//   8-B unit ^= (d>>1)&15 (ds_read_b64 conflict-free; an odd key swaps the two halves of the 16-B write).
+//
+// vk_attn_temporal_bf16 -- per-pixel attention over the T (<=32) frames (VideoTransformerBlock.attn1;
+//   vwm/modules/video_attention.py:116-127, attention.py:384-399): one wave per (batch, pixel, head); Q/K
+//   fragments are loaded straight from HBM (rows are frames, stride S*ld), V goes through a 4 KiB wave-private
+//   LDS tile and is gathered in the accumulator's key order. HBM-bound by construction (12.5 FLOP/B).
+#include "common.h"
+#include "vista_hip.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+__device__ __forceinline__ bf16x8_t make_frag(uint2 a, uint2 b) {
+    uint4 v = make_uint4(a.x, a.y, b.x, b.y);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                               const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
+                                                               int n_img, int heads, int S, int ldq, int ldk, int ldo,
+                                                               float scale_log2) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int nqb = (S + 127) >> 7;
+    const int logical = xcd_remap(blockIdx.x, nqb * n_img * heads);
+    const int bh = logical / nqb, qb = logical - bh * nqb;
+    const int img = bh / heads, head = bh - img * heads;
+
+    // ---- Q fragments (B operand: column = query row, 8 consecutive d at 16*ks + 8*lh) ----
+    const int q0 = qb * 128 + wave * 32;
+    int qrow = q0 + l31;
+    const bool q_ok = qrow < S;
+    if (!q_ok) qrow = S - 1;
+    const uint16_t* qptr = q + ((size_t)img * S + qrow) * ldq + head * 64 + 8 * lh;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qptr + 16 * ks);
+
+    // ---- K / V^T staging: thread owns 16-B chunk lc of rows lr, lr+32 ----
+    const int lc = tid & 7, lr = tid >> 3;
+    const uint16_t* kbase = k + (size_t)img * S * ldk + head * 64 + lc * 8;
+    const uint16_t* vbase = vt + ((size_t)(img * heads + head) * 64) * S + lc * 8;
+    const int ksw = (lr >> 1) & 7;          // K row swizzle (invariant under +32)
+    const int vg = (lr >> 1) & 15;          // V^T unit swizzle of row d=lr   (row d+32 has the same (d>>1)&15)
+    const int k_st = lr * 128 + ((lc ^ ksw) << 4);
+    const int v_st = lr * 128 + ((lc ^ (vg >> 1)) << 4);
+
+    uint4 rk[2], rv[2];
+    auto load_tile = [&](int t) {
+        const int key0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = key0 + lr + 32 * i;
+            rk[i] = (key < S) ? *(const uint4*)(kbase + (size_t)key * ldk) : make_uint4(0, 0, 0, 0);
+            const int kk = key0 + lc * 8;
+            rv[i] = (kk < S) ? *(const uint4*)(vbase + (size_t)(lr + 32 * i) * S + kk) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* sK = smem + stage * 16384;
+        char* sV = sK + 8192;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(uint4*)(sK + k_st + i * 32 * 128) = rk[i];
+            uint4 v = rv[i];
+            if (vg & 1) v = make_uint4(v.z, v.w, v.x, v.y);
+            *(uint4*)(sV + v_st + i * 32 * 128) = v;
+        }
+    };
+
+    // fragment read offsets
+    const int fsw = (l31 >> 1) & 7;
+    int kfrag_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kfrag_off[ks] = l31 * 128 + (((ks * 2 + lh) ^ fsw) << 4);
+    const int fvg = (l31 >> 1) & 15;
+    int vfrag_off[4][2];
+#pragma unroll
+    for (int J = 0; J < 4; ++J) {
+        vfrag_off[J][0] = l31 * 128 + (((4 * J + lh) ^ fvg) << 3);
+        vfrag_off[J][1] = l31 * 128 + (((4 * J + 2 + lh) ^ fvg) << 3);
+    }
+
+    f32x16_t oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    const int nt = (S + 63) >> 6;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int stage = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        const char* sK = smem + stage * 16384;
+        const char* sV = sK + 8192;
+
+        // ---- S^T[key][q] = K . Q^T ----
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[c][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(sK + c * 32 * 128 + kfrag_off[ks]);
+                sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[c], 0, 0, 0);
+            }
+        }
+        if (t == nt - 1 && (S & 63)) {  // mask keys past the end of the sequence (last tile only)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= S) sacc[c][r] = NEG_BIG;
+                }
+        }
+
+        // ---- online softmax: the lane's 32 scores all belong to query column l31 ----
+        float mx = sacc[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = fmaxf(mx * scale_log2, NEG_BIG);
+        if (__any(mx > m_run)) {  // wave-uniform: rescale only when some row max grew (alpha == 1 otherwise)
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = fast_exp2(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = fast_exp2(fmaf(sacc[c][r], scale_log2, -m_run));
+                sacc[c][r] = pv;
+                psum += pv;
+            }
+        l_run += psum;
+
+        // ---- P^T fragments: k-step J holds accumulator regs 8*(J&1)..+7 of key subtile J>>1 ----
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int J = 0; J < 4; ++J) {
+            const int c = J >> 1, r0 = 8 * (J & 1);
+            uint4 v;
+            v.x = pack_bf16(sacc[c][r0 + 0], sacc[c][r0 + 1]);
+            v.y = pack_bf16(sacc[c][r0 + 2], sacc[c][r0 + 3]);
+            v.z = pack_bf16(sacc[c][r0 + 4], sacc[c][r0 + 5]);
+            v.w = pack_bf16(sacc[c][r0 + 6], sacc[c][r0 + 7]);
+            pf[J] = __builtin_bit_cast(bf16x8_t, v);
+        }
+
+        // ---- O^T[d][q] += V^T . P^T ----
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                const uint2 va = *(const uint2*)(sV + d * 32 * 128 + vfrag_off[J][0]);
+                const uint2 vb = *(const uint2*)(sV + d * 32 * 128 + vfrag_off[J][1]);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(make_frag(va, vb), pf[J], oacc[d], 0, 0, 0);
+            }
+        }
+
+        if (t + 1 < nt) store_tile(stage ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q_ok) {
+        uint16_t* optr = o + ((size_t)img * S + qrow) * ldo + head * 64 + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack_bf16(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+                w.y = pack_bf16(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+                *(uint2*)(optr + 32 * d + 8 * g) = w;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o, int B, int T,
+                                                            int S, int heads, int ld, int k_off, int v_off, int ldo,
+                                                            float scale_log2, long long nprob, int iters) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 4096];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    char* sV = smem + wave * 4096;
+    const bool t_ok = l31 < T;
+
+    for (int it = 0; it < iters; ++it) {
+        long long prob = ((long long)it * gridDim.x + blockIdx.x) * 4 + wave;
+        const bool active = prob < nprob;
+        if (!active) prob = nprob - 1;
+        const int head = (int)(prob % heads);
+        const long long bs = prob / heads;
+        const int s = (int)(bs % S);
+        const int b = (int)(bs / S);
+        const size_t row0 = (size_t)b * T * S + s;  // row of frame t = row0 + t*S
+
+        // Q (B operand) and K (A operand) fragments straight from HBM: row = frame l31, 8 d at 16ks + 8lh
+        bf16x8_t qf[4], kf[4];
+        {
+            const uint16_t* rp = qkv + (row0 + (size_t)(t_ok ? l31 : 0) * S) * ld + head * 64 + 8 * lh;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 a = *(const uint4*)(rp + 16 * ks);
+                uint4 c = *(const uint4*)(rp + k_off + 16 * ks);
+                if (!t_ok) { a = make_uint4(0, 0, 0, 0); c = make_uint4(0, 0, 0, 0); }
+                qf[ks] = __builtin_bit_cast(bf16x8_t, a);
+                kf[ks] = __builtin_bit_cast(bf16x8_t, c);
+            }
+        }
+        // V tile [32 frames][64 d] -> wave-private LDS (rows >= T zero)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cidx = lane + 64 * i;
+            const int vr = cidx >> 3, vc = cidx & 7;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (vr < T) v = *(const uint4*)(qkv + (row0 + (size_t)vr * S) * ld + v_off + head * 64 + vc * 8);
+            *(uint4*)(sV + vr * 128 + vc * 16) = v;
+        }
+
+        f32x16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
+
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (key >= T) sacc[r] = NEG_BIG;
+            mx = fmaxf(mx, sacc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mb = mx * scale_log2;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float pv = fast_exp2(fmaf(sacc[r], scale_log2, -mb));
+            if (key >= T) pv = 0.f;
+            sacc[r] = pv;
+            psum += pv;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        const float inv = 1.f / psum;
+
+        bf16x8_t pf[2];
+#pragma unroll
+        for (int J = 0; J < 2; ++J) {
+            uint4 v;
+            v.x = pack_bf16(sacc[8 * J + 0], sacc[8 * J + 1]);
+            v.y = pack_bf16(sacc[8 * J + 2], sacc[8 * J + 3]);
+            v.z = pack_bf16(sacc[8 * J + 4], sacc[8 * J + 5]);
+            v.w = pack_bf16(sacc[8 * J + 6], sacc[8 * J + 7]);
+            pf[J] = __builtin_bit_cast(bf16x8_t, v);
+        }
+
+        __syncthreads();  // V tile visible (uniform trip count: every wave reaches this)
+
+        f32x16_t oacc[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                // V^T fragment in accumulator key order: element i <-> frame 16J + 8*(i>>2) + 4*lh + (i&3)
+                uint32_t w[4];
+#pragma unroll
+                for (int i2 = 0; i2 < 4; ++i2) {
+                    const int ka = 16 * J + 8 * ((2 * i2) >> 2) + 4 * lh + ((2 * i2) & 3);
+                    const uint16_t lo = *(const uint16_t*)(sV + ka * 128 + (32 * d + l31) * 2);
+                    const uint16_t hi = *(const uint16_t*)(sV + (ka + 1) * 128 + (32 * d + l31) * 2);
+                    w[i2] = (uint32_t)lo | ((uint32_t)hi << 16);
+                }
+                const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v), pf[J], oacc[d], 0, 0, 0);
+            }
+        }
+        if (active && t_ok) {
+            uint16_t* optr = o + (row0 + (size_t)l31 * S) * ldo + head * 64 + 4 * lh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w2;
+                    w2.x = pack_bf16(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+                    w2.y = pack_bf16(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+                    *(uint2*)(optr + 32 * d + 8 * g) = w2;
+                }
+        }
+        __syncthreads();  // LDS tile free for the next problem
+    }
+}
+
+}  // namespace
+
+extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
+                                    int32_t S, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream_) {
+    if (!q || !k || !vt || !o || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;
+    if ((S % 8) != 0 || (ldq % 8) != 0 || (ldk % 8) != 0 || (ldo % 4) != 0) return VK_EINVAL;
+    const int nqb = (S + 127) / 128;
+    const long long nblk = (long long)nqb * n_img * heads;
+    if (nblk > 0x7fffffffLL) return VK_EINVAL;
+    hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)q,
+                       (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
+extern "C" int vk_attn_temporal_bf16(const void* qkv, void* o, int32_t B, int32_t T, int32_t S, int32_t heads, int32_t ld,
+                                     int32_t k_off, int32_t v_off, int32_t ldo, float scale, void* stream_) {
+    if (!qkv || !o || B <= 0 || T <= 0 || T > 32 || S <= 0 || heads <= 0) return VK_EINVAL;
+    if ((ld % 8) != 0 || (k_off % 8) != 0 || (v_off % 8) != 0 || (ldo % 4) != 0) return VK_EINVAL;
+    const long long nprob = (long long)B * S * heads;
+    const long long want = (nprob + 3) / 4;
+    const long long cap = 256LL * 16;  // 16 workgroups per CU keeps plenty of loads in flight
+    const int grid = (int)(want < cap ? want : cap);
+    const int iters = (int)((want + grid - 1) / grid);
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)qkv, (uint16_t*)o, B, T,
+                       S, heads, ld, k_off, v_off, ldo, scale * LOG2E, nprob, iters);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}

@@ -1,0 +1,65 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the Vista denoising hot path.
+// Everything here is written for MI355X only: 64-lane wavefronts, MFMA 32x32x16 bf16, 160 KiB LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // one MFMA A/B operand (8 bf16, 4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+#define VK_WAVE 64
+
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t u) { return __builtin_bit_cast(float, ((uint32_t)u) << 16); }
+
+// two fp32 -> packed bf16x2 (round-to-nearest-even; lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    f32x2_t v = {a, b};
+    bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float a) { return (uint16_t)(pack_bf16(a, 0.f) & 0xffffu); }
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bf16_lo(v.x); f[1] = bf16_hi(v.x);
+    f[2] = bf16_lo(v.y); f[3] = bf16_hi(v.y);
+    f[4] = bf16_lo(v.z); f[5] = bf16_hi(v.z);
+    f[6] = bf16_lo(v.w); f[7] = bf16_hi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack_bf16(f[0], f[1]); v.y = pack_bf16(f[2], f[3]);
+    v.z = pack_bf16(f[4], f[5]); v.w = pack_bf16(f[6], f[7]);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// exact (erf) GELU, as F.gelu default in the reference (vwm/modules/attention.py:92)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// XCD-aware, bijective block remap (8 XCDs, block b is observed on XCD b%8): gives each XCD a
+// contiguous range of logical tile ids so neighbouring tiles share that XCD's private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int nx = 8;
+    int xcd = bid % nx, slot = bid / nx;
+    int q = nblk / nx, r = nblk % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+// error codes returned by the C-ABI launchers
+#define VK_OK 0
+#define VK_EINVAL (-22)
+#define VK_ELAUNCH (-5)
+
+#define VK_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return VK_ELAUNCH; } while (0)

@@ -1,0 +1,315 @@
+// bf16 MFMA GEMM family for the VideoUNet hot path (gfx950):
+//   out[m][n] = epilogue( sum_k A(m,k) * W[n][k] )
+// A(m,k) is produced by one of three loaders, all over token-major (NHWC) bf16 activations:
+//   DENSE      A[m][k]                       nn.Linear / 1x1 conv     (vwm/modules/attention.py:344-346,421; openaimodel.py:241)
+//   CONV3X3    implicit-GEMM 3x3 conv, pad 1, stride 1|2, optional fused nearest x2 upsample of the source
+//                                            (openaimodel.py:198,232 ResBlock convs; :136 Downsample; :100-102 Upsample)
+//   TEMPORAL3  3x1x1 conv over frames, pad (1,0,0)   (video_model.py:38-52 time_stack)
+// W is [Npad][K] with K contiguous (= nn.Linear.weight layout; conv weights are packed [Cout][tap][Cin]).
+//
+// Tiling: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 bf16 tiles, fp32 accumulate.
+// LDS: two stages of (A 16 KiB + W 16 KiB); rows are 128 B (64 bf16) and the 16-B chunk index is XOR-swizzled
+// with (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free. Global->LDS goes through registers
+// (prefetch tile t+1 while computing tile t; one barrier per K-step).
+// The MFMA is issued "swapped" (weights are the row/A operand, activations the column/B operand) so that a lane
+// owns one output row m and 4 consecutive output columns per accumulator quad -> 8-byte bf16x4 stores and
+// per-lane-contiguous fused epilogues (bias, per-image row vector, residuals, GEGLU).
+#include "common.h"
+#include "vista_hip.h"
+
+namespace {
+
+enum { AMODE_DENSE = 0, AMODE_CONV3X3 = 1, AMODE_TEMPORAL3 = 2 };
+enum { EPI_LINEAR = 0, EPI_GEGLU = 1, EPI_TRANS = 2 };
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = 32768;  // A tile 16 KiB + W tile 16 KiB
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int AMODE, int EPI, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tilesN = (p.N + BN - 1) / BN;
+    const int tilesM = (p.M + BM - 1) / BM;
+    const int logical = xcd_remap(blockIdx.x, tilesM * tilesN);
+    const int tn = logical % tilesN, tm = logical / tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const uint16_t* __restrict__ Ag = (const uint16_t*)p.A;
+    const uint16_t* __restrict__ Wg = (const uint16_t*)p.Wt;
+
+    // ---- per-thread global->LDS staging assignment: chunk lc of rows lr + 32*i ----
+    const int lc = tid & 7;
+    const int lr = tid >> 3;
+    const int st_off = lds_off(lr, lc);  // (row>>1)&7 is invariant under +32*i
+
+    const uint16_t* wptr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wptr[i] = Wg + (size_t)(n0 + lr + 32 * i) * p.K + lc * 8;
+
+    // A-row state
+    const uint16_t* aptr[4];
+    int a_y0[4], a_x0[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + lr + 32 * i;
+        a_ok[i] = m < p.M;
+        if (m >= p.M) m = p.M - 1;
+        if (AMODE == AMODE_DENSE) {
+            aptr[i] = Ag + (size_t)m * p.lda + lc * 8;
+            a_y0[i] = a_x0[i] = 0;
+        } else if (AMODE == AMODE_CONV3X3) {
+            const int hw = p.Hout * p.Wout;
+            const int img = m / hw;
+            const int rem = m - img * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_y0[i] = oy * p.stride - 1;
+            a_x0[i] = ox * p.stride - 1;
+            aptr[i] = Ag + (size_t)img * p.H * p.Wd * p.Cin + lc * 8;
+        } else {  // TEMPORAL3: m = (b*T + t)*S + s
+            const int fr = m / p.S;
+            a_y0[i] = fr % p.T;  // frame index t
+            a_x0[i] = 0;
+            aptr[i] = Ag + (size_t)m * p.Cin + lc * 8;
+        }
+    }
+
+    uint4 ra[4], rw[4];
+    int tap = 0, c0 = 0;  // (tap, channel offset) of the current K-step for the conv loaders
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rw[i] = *(const uint4*)(wptr[i] + k0);
+        if (AMODE == AMODE_DENSE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = *(const uint4*)(aptr[i] + k0);
+        } else if (AMODE == AMODE_CONV3X3) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int sh = p.ups - 1;
+            const int He = p.H << sh, We = p.Wd << sh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                const bool ok = a_ok[i] && iy >= 0 && iy < He && ix >= 0 && ix < We;
+                const int sy = iy >> sh, sx = ix >> sh;
+                if (ok) ra[i] = *(const uint4*)(aptr[i] + ((size_t)(sy * p.Wd + sx) * p.Cin + c0));
+                else ra[i] = make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const int dt = tap - 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = a_y0[i] + dt;
+                const bool ok = a_ok[i] && t >= 0 && t < p.T;
+                if (ok) ra[i] = *(const uint4*)(aptr[i] + ((ptrdiff_t)dt * p.S * p.Cin + c0));
+                else ra[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        c0 += BK;
+        if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    };
+    auto store_tile = [&](int stage) {
+        char* sA = smem + stage * STAGE_BYTES;
+        char* sW = sA + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(uint4*)(sA + st_off + i * 32 * 128) = ra[i];
+            *(uint4*)(sW + st_off + i * 32 * 128) = rw[i];
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // X = MFMA row operand, Y = MFMA column operand. Normal: X = weights, Y = activations. TRANS: swapped.
+    const int xoff = (EPI == EPI_TRANS) ? wm * 64 : wn * 64;
+    const int yoff = (EPI == EPI_TRANS) ? wn * 64 : wm * 64;
+    const int xbase = (EPI == EPI_TRANS) ? 0 : 16384;   // X tile lives in sA (TRANS) or sW
+    const int ybase = (EPI == EPI_TRANS) ? 16384 : 0;
+    const int sw = (l31 >> 1) & 7;
+    int frag_off[4];  // byte offset of k-substep ks inside a row
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) frag_off[ks] = ((ks * 2 + lh) ^ sw) << 4;
+    const int xrow_off = (xoff + l31) * 128, yrow_off = (yoff + l31) * 128;
+
+    const int nk = p.K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const char* sb = smem + stage * STAGE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t xf[2], yf[2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                xf[f] = *(const bf16x8_t*)(sb + xbase + xrow_off + f * 32 * 128 + frag_off[ks]);
+                yf[f] = *(const bf16x8_t*)(sb + ybase + yrow_off + f * 32 * 128 + frag_off[ks]);
+            }
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj)
+                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(stage ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------- epilogue -------------------------------
+    // accumulator element r = 4*g + e of tile (fi,fj): X-row = 32*fi + 8*g + 4*lh + e, Y-row = 32*fj + l31
+    if (EPI == EPI_LINEAR) {
+        const float* __restrict__ bias = p.bias;
+        const float* __restrict__ rowvec = p.rowvec;
+        const uint16_t* __restrict__ res1 = (const uint16_t*)p.res1;
+        const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+            const int m = m0 + wm * 64 + fj * 32 + l31;
+            if (m >= p.M) continue;
+            const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 64 + fi * 32 + 8 * g + 4 * lh;
+                    if (n >= p.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
+                    if (bias) {
+                        const float4 b = *(const float4*)(bias + n);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (rv) {
+                        const float4 b = *(const float4*)(rv + n);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (res1) {
+                        const uint2 r = *(const uint2*)(res1 + (size_t)m * p.ld_res1 + n);
+                        v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                    if (res2) {
+                        const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
+                        v[0] += p.beta * bf16_lo(r.x); v[1] += p.beta * bf16_hi(r.x);
+                        v[2] += p.beta * bf16_lo(r.y); v[3] += p.beta * bf16_hi(r.y);
+                    }
+                    if (OUT_F32) {
+                        *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 o;
+                        o.x = pack_bf16(v[0], v[1]);
+                        o.y = pack_bf16(v[2], v[3]);
+                        *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + n) = o;
+                    }
+                }
+            }
+        }
+    } else if (EPI == EPI_GEGLU) {
+        // packed weight rows: tile of 128 = 2 x [32 value rows | 32 gate rows]; fi=0 value, fi=1 gate
+        const float* __restrict__ bias = p.bias;
+        const int nout = p.N >> 1;
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+            const int m = m0 + wm * 64 + fj * 32 + l31;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int np = n0 + wn * 64 + 8 * g + 4 * lh;       // packed row of the value part
+                const int nc = (n0 >> 1) + wn * 32 + 8 * g + 4 * lh;  // output column
+                if (nc >= nout) continue;
+                float a[4], gt[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = acc[0][fj][4 * g + e]; gt[e] = acc[1][fj][4 * g + e]; }
+                if (bias) {
+                    const float4 ba = *(const float4*)(bias + np);
+                    const float4 bg = *(const float4*)(bias + np + 32);
+                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                }
+                uint2 o;
+                o.x = pack_bf16(a[0] * gelu_erf_f(gt[0]), a[1] * gelu_erf_f(gt[1]));
+                o.y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
+                *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + nc) = o;
+            }
+        }
+    } else {  // EPI_TRANS: out[img][n][key], key = m % S contiguous
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj) {
+            const int n = n0 + wn * 64 + fj * 32 + l31;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = m0 + wm * 64 + fi * 32 + 8 * g + 4 * lh;
+                    if (m >= p.M) continue;
+                    const int img = m / p.S;
+                    const int key = m - img * p.S;
+                    uint2 o;
+                    o.x = pack_bf16(acc[fi][fj][4 * g + 0], acc[fi][fj][4 * g + 1]);
+                    o.y = pack_bf16(acc[fi][fj][4 * g + 2], acc[fi][fj][4 * g + 3]);
+                    *(uint2*)((uint16_t*)p.out + ((size_t)img * p.N + n) * p.S + key) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int AMODE, int EPI, bool OUT_F32>
+int launch(const VkGemmDesc* d, hipStream_t stream) {
+    const int tilesN = (d->N + BN - 1) / BN;
+    const int tilesM = (d->M + BM - 1) / BM;
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32>), dim3(tilesM * tilesN), dim3(256), 0, stream, *d);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
+}  // namespace
+
+extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0) return VK_EINVAL;
+    if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
+    if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
+    if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;
+    if (d->amode == AMODE_TEMPORAL3 && (d->K != 3 * d->Cin || d->T <= 0 || d->S <= 0)) return VK_EINVAL;
+    if (d->rowvec && d->rows_per_vec <= 0) return VK_EINVAL;
+    const bool f32 = d->out_f32 != 0;
+    switch (d->epi) {
+        case EPI_LINEAR:
+            if ((d->ldc % 4) != 0) return VK_EINVAL;
+            if (d->amode == AMODE_DENSE) return f32 ? launch<AMODE_DENSE, EPI_LINEAR, true>(d, stream) : launch<AMODE_DENSE, EPI_LINEAR, false>(d, stream);
+            if (d->amode == AMODE_CONV3X3) return f32 ? launch<AMODE_CONV3X3, EPI_LINEAR, true>(d, stream) : launch<AMODE_CONV3X3, EPI_LINEAR, false>(d, stream);
+            if (d->amode == AMODE_TEMPORAL3 && !f32) return launch<AMODE_TEMPORAL3, EPI_LINEAR, false>(d, stream);
+            return VK_EINVAL;
+        case EPI_GEGLU:
+            if (d->amode != AMODE_DENSE || f32 || (d->N % 128) != 0) return VK_EINVAL;
+            return launch<AMODE_DENSE, EPI_GEGLU, false>(d, stream);
+        case EPI_TRANS:
+            if (d->amode != AMODE_DENSE || f32 || d->S <= 0 || (d->S % 4) != 0) return VK_EINVAL;
+            return launch<AMODE_DENSE, EPI_TRANS, false>(d, stream);
+    }
+    return VK_EINVAL;
+}

@@ -1,0 +1,216 @@
+// GroupNorm(32)+SiLU and LayerNorm over token-major bf16 activations (gfx950). All HBM-bound: 16-B (8 x bf16)
+// coalesced accesses, fp32 statistics (the reference's GroupNorm32 computes in fp32:
+// vwm/modules/diffusionmodules/util.py:214-216), wave64 shuffle reductions.
+//
+// GroupNorm: x[n_img][S][C], 32 groups of cpg = C/32 channels; statistics per (image-group, channel-group) where an
+// image-group is `frames_per_group` consecutive images -- 1 for the 2-D norms, T for the temporal ResBlock's 5-D norm
+// whose statistics span (C/32, T, H, W) (openaimodel.py:196,228 on `b c t h w`). Two launches:
+//   stats : every thread owns one fixed 16-B channel chunk and strides over tokens, keeping 8 per-channel fp32
+//           partial (sum, sumsq) pairs -> folded per group into LDS atomics -> one global atomic per group.
+//   apply : same ownership; per-channel scale/shift folded once into 16 registers, then a pure streaming pass
+//           y = silu(x*a + b).
+#include "common.h"
+#include "vista_hip.h"
+
+namespace {
+
+constexpr int GN_TOK = 128;  // tokens per workgroup
+
+__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ stats, int S, int C, int CG, int R,
+                                int frames_per_group) {
+    __shared__ float lsum[32], lsq[32];
+    const int tid = threadIdx.x;
+    if (tid < 32) { lsum[tid] = 0.f; lsq[tid] = 0.f; }
+    __syncthreads();
+    const int img = blockIdx.y;
+    const int tok0 = blockIdx.x * GN_TOK;
+    const int tok1 = min(tok0 + GN_TOK, S);
+    const int chunk = tid % CG, r = tid / CG;
+    const int cpg = C >> 5;
+    if (r < R) {
+        float sm[8], sq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
+        const uint16_t* p = x + ((size_t)img * S) * C + chunk * 8;
+        for (int t = tok0 + r; t < tok1; t += R) {
+            const uint4 v = *(const uint4*)(p + (size_t)t * C);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] = fmaf(f[e], f[e], sq[e]); }
+        }
+        // fold the 8 per-channel partials into their groups (a chunk may straddle several groups for any cpg)
+        int gprev = (chunk * 8) / cpg;
+        float as = 0.f, aq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (chunk * 8 + e) / cpg;
+            if (g != gprev) {
+                atomicAdd(&lsum[gprev], as);
+                atomicAdd(&lsq[gprev], aq);
+                as = 0.f; aq = 0.f; gprev = g;
+            }
+            as += sm[e]; aq += sq[e];
+        }
+        atomicAdd(&lsum[gprev], as);
+        atomicAdd(&lsq[gprev], aq);
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float* st = stats + (size_t)(img / frames_per_group) * 64;
+        atomicAdd(st + tid, lsum[tid]);
+        atomicAdd(st + 32 + tid, lsq[tid]);
+    }
+}
+
+__global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ stats, int S, int C, int CG, int R,
+                                int frames_per_group, float eps, int do_silu) {
+    const int tid = threadIdx.x;
+    const int img = blockIdx.y;
+    const int tok0 = blockIdx.x * GN_TOK;
+    const int tok1 = min(tok0 + GN_TOK, S);
+    const int chunk = tid % CG, r = tid / CG;
+    if (r >= R) return;
+    const int cpg = C >> 5;
+    const float inv_cnt = 1.f / ((float)cpg * (float)S * (float)frames_per_group);
+    const float* st = stats + (size_t)(img / frames_per_group) * 64;
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = chunk * 8 + e;
+        const int g = c / cpg;
+        const float mean = st[g] * inv_cnt;
+        const float var = fmaxf(st[32 + g] * inv_cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        a[e] = gamma[c] * rstd;
+        b[e] = beta[c] - mean * a[e];
+    }
+    const size_t base = ((size_t)img * S) * C + chunk * 8;
+    for (int t = tok0 + r; t < tok1; t += R) {
+        const uint4 v = *(const uint4*)(x + base + (size_t)t * C);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float u = fmaf(f[e], a[e], b[e]);
+            f[e] = do_silu ? silu_f(u) : u;
+        }
+        *(uint4*)(y + base + (size_t)t * C) = pack8(f);
+    }
+}
+
+// LayerNorm: one wave per row, NCH 16-B chunks per lane (C <= 512*NCH). Two-pass (mean, centred variance) in
+// registers. Optional per-image pre-add vector and write-back of the (bf16-rounded) sum.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y,
+                                                        uint16_t* __restrict__ sum_out, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ addvec, int rows,
+                                                        int C, int rows_per_vec, int ldv, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int CG = C >> 3;
+    const int nw = gridDim.x * 4;
+    float gm[NCH][8], bt[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int ch = lane + 64 * j;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gm[j][e] = (ch < CG) ? gamma[ch * 8 + e] : 0.f;
+            bt[j][e] = (ch < CG) ? beta[ch * 8 + e] : 0.f;
+        }
+    }
+    const float inv_c = 1.f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += nw) {
+        float f[NCH][8];
+        float s = 0.f;
+        const float* av = addvec ? addvec + (size_t)(row / rows_per_vec) * ldv : nullptr;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < CG) {
+                const uint4 v = *(const uint4*)(x + (size_t)row * C + ch * 8);
+                unpack8(v, f[j]);
+                if (av) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[j][e] += av[ch * 8 + e];
+                    const uint4 w = pack8(f[j]);
+                    if (sum_out) *(uint4*)(sum_out + (size_t)row * C + ch * 8) = w;
+                    unpack8(w, f[j]);  // normalise the bf16-rounded sum (what later residuals read)
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[j][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[j][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < CG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < CG) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = fmaf((f[j][e] - mean) * rstd, gm[j][e], bt[j][e]);
+                *(uint4*)(y + (size_t)row * C + ch * 8) = pack8(o);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws, int32_t n_img,
+                                      int32_t S, int32_t C, int32_t frames_per_group, float eps, int32_t silu, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !gamma || !beta || !stats_ws) return VK_EINVAL;
+    if (n_img <= 0 || S <= 0 || C <= 0 || (C % 32) != 0 || (C % 8) != 0 || C > 8192) return VK_EINVAL;
+    if (frames_per_group <= 0 || (n_img % frames_per_group) != 0) return VK_EINVAL;
+    const int CG = C / 8;
+    if (CG > 1024) return VK_EINVAL;
+    int R = 256 / CG;
+    if (R < 1) R = 1;
+    const int threads = ((CG * R + 63) / 64) * 64;
+    const size_t nstat = (size_t)(n_img / frames_per_group) * 64;
+    if (hipMemsetAsync(stats_ws, 0, nstat * sizeof(float), stream) != hipSuccess) return VK_ELAUNCH;
+    dim3 grid((S + GN_TOK - 1) / GN_TOK, n_img);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 0, stream, (const uint16_t*)x, stats_ws, S, C, CG, R, frames_per_group);
+    VK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, (const uint16_t*)x, (uint16_t*)y, gamma, beta,
+                       (const float*)stats_ws, S, C, CG, R, frames_per_group, eps, silu);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
+extern "C" int vk_layernorm_bf16(const void* x, void* y, void* sum_out, const float* gamma, const float* beta, const float* addvec,
+                                 int32_t rows, int32_t C, int32_t rows_per_vec, int32_t ldv, float eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !y || !gamma || !beta || rows <= 0 || C <= 0 || (C % 8) != 0 || C > 1536) return VK_EINVAL;
+    if (addvec && rows_per_vec <= 0) return VK_EINVAL;
+    const int CG = C / 8;
+    const int nch = (CG + 63) / 64;
+    long long want = ((long long)rows + 3) / 4;
+    const long long cap = 256LL * 8;
+    const int grid = (int)(want < cap ? want : cap);
+#define LN_LAUNCH(N)                                                                                                              \
+    hipLaunchKernelGGL(layernorm_kernel<N>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, (uint16_t*)y, (uint16_t*)sum_out, \
+                       gamma, beta, addvec, rows, C, rows_per_vec, ldv, eps)
+    if (nch == 1) LN_LAUNCH(1);
+    else if (nch == 2) LN_LAUNCH(2);
+    else LN_LAUNCH(3);
+#undef LN_LAUNCH
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}

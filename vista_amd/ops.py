@@ -1,0 +1,388 @@
+"""Torch-tensor front end of the C-ABI kernels (include/vista_hip.h).
+
+PyTorch is used for device memory (caching allocator), streams and views only; every arithmetic op below is a
+hand-written gfx950 kernel in libvista_hip.so. Activations are token-major bf16: (n_img, S=H*W, C), C contiguous.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import VkGemmDesc, check
+
+AMODE_DENSE, AMODE_CONV3X3, AMODE_TEMPORAL3 = 0, 1, 2
+EPI_LINEAR, EPI_GEGLU, EPI_TRANS = 0, 1, 2
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need(t, dtype, name):
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise _lib.VistaHipError(f"{name}: tensor is on {t.device}; vista_amd kernels run on the MI355X only (no CPU fallback)")
+
+
+def _rows2d(t, name):
+    """(…, C) tensor whose rows are uniformly strided -> (rows, ld)."""
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dim must be contiguous")
+    t2 = t.reshape(-1, t.shape[-1]) if t.is_contiguous() else t
+    if t2.dim() != 2:
+        raise ValueError(f"{name}: pass a 2-D strided view")
+    return t2, t2.stride(0)
+
+
+def ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------------------------- weight packing
+class PackedWeight:
+    """bf16 [ceil128(N)][K] weight (K contiguous) + f32 bias, laid out for vk_gemm_bf16."""
+
+    __slots__ = ("wt", "bias", "N", "K", "geglu")
+
+    def __init__(self, wt, bias, N, K, geglu=False):
+        self.wt, self.bias, self.N, self.K, self.geglu = wt, bias, N, K, geglu
+
+
+def _finish_pack(w2d, bias, device, geglu=False):
+    N, K = w2d.shape
+    Kp = ceil_to(K, 64)
+    Np = ceil_to(N, 128)
+    wt = torch.zeros((Np, Kp), dtype=BF16, device=device)
+    wt[:N, :K] = w2d.to(device=device, dtype=BF16)
+    b = None
+    if bias is not None:
+        b = torch.zeros((Np,), dtype=F32, device=device)
+        b[:N] = bias.to(device=device, dtype=F32)
+    return PackedWeight(wt, b, N, Kp, geglu)
+
+
+def pack_linear(weight, bias=None, device="cuda"):
+    """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1])."""
+    return _finish_pack(weight.detach().reshape(weight.shape[0], -1).float(), None if bias is None else bias.detach().float(), device)
+
+
+def pack_linear_cat(weights, device="cuda"):
+    """Several bias-free Linear weights sharing the input, concatenated along N (fused q|k or q|k|v projection)."""
+    return _finish_pack(torch.cat([w.detach().float() for w in weights], 0), None, device)
+
+
+def pack_geglu(weight, bias, device="cuda"):
+    """GEGLU.proj weight [2*Nout][K]: value rows then gate rows (attention.py:85-92). Packed so that every 128-row
+    tile holds 2 x [32 value rows | their 32 gate rows] and the GEMM epilogue can form value*gelu(gate) in-lane."""
+    w = weight.detach().float()
+    b = bias.detach().float()
+    n2, _ = w.shape
+    nout = n2 // 2
+    if nout % 64:
+        raise ValueError("GEGLU width must be a multiple of 64")
+    idx = torch.arange(nout).reshape(-1, 32)           # blocks of 32 output columns
+    perm = torch.stack([idx, idx + nout], 1).reshape(-1)  # [v-block0, g-block0, v-block1, g-block1, ...]
+    return _finish_pack(w[perm], b[perm], device, geglu=True)
+
+
+def pack_conv3x3(weight, bias=None, cin_pad=None, device="cuda"):
+    """nn.Conv2d weight [Cout][Cin][3][3] -> [Cout][ky][kx][Cin(_pad)]."""
+    w = weight.detach().float().permute(0, 2, 3, 1).contiguous()  # Cout, ky, kx, Cin
+    cout, _, _, cin = w.shape
+    cp = cin_pad or ceil_to(cin, 64)
+    if cp != cin:
+        w = torch.nn.functional.pad(w, (0, cp - cin))
+    return _finish_pack(w.reshape(cout, 9 * cp), None if bias is None else bias.detach().float(), device)
+
+
+def pack_conv_t3(weight, bias=None, device="cuda"):
+    """nn.Conv3d weight [Cout][Cin][3][1][1] -> [Cout][kt][Cin]."""
+    w = weight.detach().float()[:, :, :, 0, 0].permute(0, 2, 1).contiguous()
+    cout, _, cin = w.shape
+    if cin % 64:
+        raise ValueError("temporal conv needs Cin % 64 == 0")
+    return _finish_pack(w.reshape(cout, 3 * cin), None if bias is None else bias.detach().float(), device)
+
+
+# ---------------------------------------------------------------------------------------------- GEMM family
+def _gemm(desc):
+    lib = _lib.load()
+    check(lib.vk_gemm_bf16(C.byref(desc), _stream()), "vk_gemm_bf16")
+
+
+def _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta):
+    d.Wt = _p(pw.wt)
+    d.bias = _p(pw.bias)
+    d.M, d.N, d.K = M, pw.N, pw.K
+    d.out = _p(out)
+    d.ldc = out.stride(0)
+    d.out_f32 = 1 if out.dtype == F32 else 0
+    d.alpha, d.beta = float(alpha), float(beta)
+    if rowvec is not None:
+        _need(rowvec, F32, "rowvec")
+        d.rowvec, d.ldv, d.rows_per_vec = _p(rowvec), rowvec.stride(0), int(rows_per_vec)
+    if res1 is not None:
+        _need(res1, BF16, "res1")
+        r, ld = _rows2d(res1, "res1")
+        d.res1, d.ld_res1 = _p(r), ld
+    if res2 is not None:
+        _need(res2, BF16, "res2")
+        r, ld = _rows2d(res2, "res2")
+        d.res2, d.ld_res2 = _p(r), ld
+
+
+def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0):
+    """out = alpha*(x @ W^T + bias + rowvec[row // rows_per_vec] + res1) + beta*res2.  x: (..., K) bf16."""
+    _need(x, BF16, "x")
+    x2, lda = _rows2d(x, "x")
+    M = x2.shape[0]
+    if x2.shape[1] != pw.K:
+        raise ValueError(f"linear: K mismatch {x2.shape[1]} vs {pw.K}")
+    if pw.geglu:
+        nout = pw.N // 2
+        if out is None:
+            out = torch.empty((M, nout), dtype=BF16, device=x.device)
+    elif out is None:
+        out = torch.empty((M, pw.N), dtype=F32 if out_f32 else BF16, device=x.device)
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x2), lda
+    d.amode = AMODE_DENSE
+    d.epi = EPI_GEGLU if pw.geglu else EPI_LINEAR
+    _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta)
+    _gemm(d)
+    return out
+
+
+def linear_vt(x, pw, S):
+    """V^T projection for spatial attention: x (n_img*S, K) -> out (n_img, N, S) bf16 (EPI_TRANS)."""
+    _need(x, BF16, "x")
+    x2, lda = _rows2d(x, "x")
+    M = x2.shape[0]
+    out = torch.empty((M // S, pw.N, S), dtype=BF16, device=x.device)
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x2), lda
+    d.amode, d.epi = AMODE_DENSE, EPI_TRANS
+    d.Wt, d.M, d.N, d.K, d.out, d.ldc, d.S = _p(pw.wt), M, pw.N, pw.K, _p(out), S, S
+    d.alpha = 1.0
+    _gemm(d)
+    return out
+
+
+def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, rowvec=None, res1=None, res2=None, alpha=1.0,
+            beta=0.0):
+    """3x3 conv, pad 1, over token-major x (n_img, H*W, Cin); `ups`=2 applies a nearest x2 upsample to the source
+    on the fly (Upsample.forward, openaimodel.py:100-102); stride 2 = Downsample (openaimodel.py:136)."""
+    _need(x, BF16, "x")
+    if not x.is_contiguous():
+        raise ValueError("conv3x3: x must be contiguous")
+    cin = x.shape[-1]
+    if pw.K != 9 * cin:
+        raise ValueError(f"conv3x3: weight K {pw.K} != 9*{cin}")
+    He, We = H * ups, W * ups
+    Hout = (He + 2 - 3) // stride + 1
+    Wout = (We + 2 - 3) // stride + 1
+    M = n_img * Hout * Wout
+    if out is None:
+        out = torch.empty((M, pw.N), dtype=F32 if out_f32 else BF16, device=x.device)
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x), cin
+    d.amode, d.epi = AMODE_CONV3X3, EPI_LINEAR
+    d.H, d.Wd, d.Cin, d.Hout, d.Wout, d.stride, d.ups = H, W, cin, Hout, Wout, stride, ups
+    _fill_epilogue(d, pw, out, M, rowvec, Hout * Wout, res1, res2, alpha, beta)
+    _gemm(d)
+    return out.view(n_img, Hout * Wout, pw.N), Hout, Wout
+
+
+def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0):
+    """3x1x1 temporal conv, pad (1,0,0) (video_model.py:38-52) over x ((b t), S, C)."""
+    _need(x, BF16, "x")
+    if not x.is_contiguous():
+        raise ValueError("conv_t3: x must be contiguous")
+    cin = x.shape[-1]
+    if pw.K != 3 * cin:
+        raise ValueError("conv_t3: weight K mismatch")
+    M = x.shape[0] * x.shape[1]
+    if out is None:
+        out = torch.empty((M, pw.N), dtype=BF16, device=x.device)
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x), cin
+    d.amode, d.epi = AMODE_TEMPORAL3, EPI_LINEAR
+    d.Cin, d.T, d.S = cin, T, S
+    _fill_epilogue(d, pw, out, M, rowvec, S, res1, res2, alpha, beta)
+    _gemm(d)
+    return out.view(x.shape[0], S, pw.N)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attn_spatial(q, k, vt, n_img, heads, S, scale=None):
+    """q, k: 2-D strided views (n_img*S, heads*64) bf16; vt (n_img, heads*64, S). Returns (n_img*S, heads*64)."""
+    _need(q, BF16, "q"); _need(k, BF16, "k"); _need(vt, BF16, "vt")
+    o = torch.empty((n_img * S, heads * 64), dtype=BF16, device=q.device)
+    lib = _lib.load()
+    check(lib.vk_attn_spatial_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), o.stride(0),
+                                   float(scale if scale is not None else 1.0 / math.sqrt(64)), _stream()), "vk_attn_spatial_bf16")
+    return o
+
+
+def attn_temporal(qkv, B, T, S, heads, scale=None):
+    """qkv: ((b t) s, 3*heads*64) bf16 row-major [q | k | v]. Returns ((b t) s, heads*64)."""
+    _need(qkv, BF16, "qkv")
+    c = heads * 64
+    o = torch.empty((B * T * S, c), dtype=BF16, device=qkv.device)
+    lib = _lib.load()
+    check(lib.vk_attn_temporal_bf16(_p(qkv), _p(o), B, T, S, heads, qkv.stride(0), c, 2 * c, o.stride(0),
+                                    float(scale if scale is not None else 1.0 / math.sqrt(64)), _stream()), "vk_attn_temporal_bf16")
+    return o
+
+
+# ---------------------------------------------------------------------------------------------- norms
+def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None):
+    """x (n_img, S, C) bf16 contiguous."""
+    _need(x, BF16, "x")
+    if not x.is_contiguous():
+        raise ValueError("groupnorm: x must be contiguous")
+    n_img, S, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    ws = torch.empty((n_img // frames_per_group) * 64, dtype=F32, device=x.device)
+    lib = _lib.load()
+    check(lib.vk_groupnorm_silu_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), n_img, S, Cc, frames_per_group, float(eps),
+                                     1 if silu else 0, _stream()), "vk_groupnorm_silu_bf16")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, addvec=None, rows_per_vec=0, want_sum=False):
+    """x (..., C) bf16 contiguous -> LN(x + addvec[row // rows_per_vec]); optionally also returns the sum."""
+    _need(x, BF16, "x")
+    if not x.is_contiguous():
+        raise ValueError("layernorm: x must be contiguous")
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if (want_sum and addvec is not None) else None
+    lib = _lib.load()
+    check(lib.vk_layernorm_bf16(_p(x), _p(y), _p(s), _p(gamma), _p(beta), _p(addvec), rows, Cc, int(rows_per_vec),
+                                addvec.stride(0) if addvec is not None else 0, float(eps), _stream()), "vk_layernorm_bf16")
+    return (y, s) if want_sum else y
+
+
+# ---------------------------------------------------------------------------------------------- elementwise
+def concat_channels(a, b):
+    _need(a, BF16, "a"); _need(b, BF16, "b")
+    if not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("concat_channels: contiguous inputs required")
+    c1, c2 = a.shape[-1], b.shape[-1]
+    rows = a.numel() // c1
+    out = torch.empty(a.shape[:-1] + (c1 + c2,), dtype=BF16, device=a.device)
+    check(_lib.load().vk_concat_channels_bf16(_p(a), _p(b), _p(out), rows, c1, c2, _stream()), "vk_concat_channels_bf16")
+    return out
+
+
+def nchw_to_tokens(x, cpad):
+    _need(x, F32, "x")
+    n, c, h, w = x.shape
+    x = x.contiguous()
+    out = torch.empty((n, h * w, cpad), dtype=BF16, device=x.device)
+    check(_lib.load().vk_nchw_to_tokens_bf16(_p(x), _p(out), n, c, h * w, cpad, _stream()), "vk_nchw_to_tokens_bf16")
+    return out
+
+
+def tokens_to_nchw(x, n_img, Cc, H, W):
+    _need(x, F32, "x")
+    out = torch.empty((n_img, Cc, H, W), dtype=F32, device=x.device)
+    check(_lib.load().vk_tokens_to_nchw_f32(_p(x), _p(out), n_img, Cc, H * W, x.stride(-2), _stream()), "vk_tokens_to_nchw_f32")
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    _need(t, F32, "t")
+    t = t.contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
+    check(_lib.load().vk_timestep_embedding_bf16(_p(t), _p(out), t.shape[0], dim, float(max_period), _stream()),
+          "vk_timestep_embedding_bf16")
+    return out
+
+
+def emb_combine(a, b, c, mask):
+    """emb = a*mask + b*(1-mask) + c ; returns (emb f32, silu(emb) bf16)."""
+    n, dim = b.shape
+    emb = torch.empty((n, dim), dtype=F32, device=b.device)
+    se = torch.empty((n, dim), dtype=BF16, device=b.device)
+    check(_lib.load().vk_emb_combine(_p(a), _p(b), _p(c), _p(mask), _p(emb), _p(se), n, dim, _stream()), "vk_emb_combine")
+    return emb, se
+
+
+def silu_to_bf16(x):
+    _need(x, F32, "x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(_lib.load().vk_silu_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "vk_silu_f32_to_bf16")
+    return y
+
+
+def cast_to_bf16(x):
+    _need(x, F32, "x")
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(_lib.load().vk_cast_f32_to_bf16(_p(x), _p(y), x.numel(), _stream()), "vk_cast_f32_to_bf16")
+    return y
+
+
+# ---- sampler-side ----
+def sampler_prepare(x, cond_frame, mask, concat_uc, concat_c, cpad, c_in, replace):
+    T, _, H, W = x.shape
+    net_in = torch.empty((2 * T, H * W, cpad), dtype=BF16, device=x.device)
+    check(_lib.load().vk_sampler_prepare(_p(x), _p(cond_frame), _p(mask), _p(concat_uc), _p(concat_c), _p(net_in), T, H * W, cpad,
+                                         float(c_in), 1 if replace else 0, _stream()), "vk_sampler_prepare")
+    return net_in
+
+
+def sampler_update(x, net_out, scale, c_out, c_skip, sigma, sigma_next):
+    T, _, H, W = x.shape
+    check(_lib.load().vk_sampler_update(_p(x), _p(net_out), _p(scale), T, H * W, net_out.stride(-2), float(c_out), float(c_skip),
+                                        float(sigma), float(sigma_next), _stream()), "vk_sampler_update")
+    return x
+
+
+def denoiser_combine(net, x, c_out, c_skip):
+    out = torch.empty_like(x)
+    n = x.shape[0]
+    check(_lib.load().vk_denoiser_combine(_p(net), _p(x), _p(c_out), _p(c_skip), _p(out), n, x.numel() // n, _stream()),
+          "vk_denoiser_combine")
+    return out
+
+
+def cfg_combine(x2, scale):
+    T = x2.shape[0] // 2
+    out = torch.empty((T,) + tuple(x2.shape[1:]), dtype=F32, device=x2.device)
+    check(_lib.load().vk_cfg_combine(_p(x2), _p(scale), _p(out), T, out.numel() // T, _stream()), "vk_cfg_combine")
+    return out
+
+
+def euler_step(x, den, sigma, sigma_next):
+    out = torch.empty_like(x)
+    n = x.shape[0]
+    check(_lib.load().vk_euler_step(_p(x), _p(den), _p(sigma), _p(sigma_next), _p(out), n, x.numel() // n, _stream()), "vk_euler_step")
+    return out
+
+
+def mask_replace(x, cond, mask):
+    out = torch.empty_like(x)
+    n = x.shape[0]
+    check(_lib.load().vk_mask_replace(_p(x), _p(cond), _p(mask), _p(out), n, x.numel() // n, _stream()), "vk_mask_replace")
+    return out
+
+
+def scale_rows(x, s):
+    out = torch.empty_like(x)
+    n = x.shape[0]
+    check(_lib.load().vk_scale_rows(_p(x), _p(s), _p(out), n, x.numel() // n, _stream()), "vk_scale_rows")
+    return out
