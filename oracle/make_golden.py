@@ -1,0 +1,143 @@
+"""Generate tests/golden/* from the REAL reference (runs only in the build container, where /root/reference exists).
+
+    python oracle/make_golden.py [--full]
+
+The reference modules are imported unmodified through oracle/ref_shim.py and run on CPU in fp32 with
+`vista_amd.synth` seeded weights (every tensor, including the reference's zero-initialised ones) and seeded inputs.
+Only OUTPUTS are stored (plus scalar known-answer values and a digest of the state-dict names/shapes): inputs and
+weights are regenerated bit-identically from their seeds wherever the goldens are consumed.
+
+Fixtures:
+  kat.json            scalar known answers: EDM sigma schedules, VScalingWithEDMcNoise, guider scales, timestep embedding
+  unet_tiny_t5.pt     VideoUNet(model_channels=64) forward, T=5, CFG batch N=10, latent 16x32, cond_mask e0
+  unet_tiny_t25.pt    same network, T=25 (N=50): exercises the 25-frame temporal attention / 5-D GroupNorm sizes
+  sampler_tiny.pt     Denoiser + VanillaCFG(2.5) + EulerEDMSampler, 3 steps, T=5, latent 16x32 (+ identity / linear guiders)
+  unet_full_t5.pt     (--full) the shipped 1.65 B-parameter configuration (configs/inference/vista.yaml) at latent 16x32, T=5
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim  # noqa: E402
+from vista_amd import synth  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+CFG = "vwm.modules.diffusionmodules."
+
+
+def unet_inputs(T, H, W, seed, sigma, n_cond=1):
+    """CFG-doubled UNet inputs exactly as the sampler hands them to the network (guiders.py:28-36, wrappers.py:25-40)."""
+    w = synth.window_inputs(T=T, H=H, W=W, seed=seed, n_cond=n_cond, trajectory=[0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2])
+    c, uc = w["c"], w["uc"]
+    x = w["noise"] * sigma
+    c_in = 1.0 / (sigma ** 2 + 1.0) ** 0.5
+    x8 = torch.cat([torch.cat([x * c_in, uc["concat"]], 1), torch.cat([x * c_in, c["concat"]], 1)], 0)
+    timesteps = torch.full((2 * T,), 0.25 * float(torch.tensor(sigma).log()))
+    context = torch.cat([uc["crossattn"], c["crossattn"]], 0)
+    y = torch.cat([uc["vector"], c["vector"]], 0)
+    mask = torch.cat([w["cond_mask"]] * 2)
+    return x8, timesteps, context, y, mask
+
+
+def seeded_ref_unet(model_channels, seed=0):
+    net = ref_shim.build_ref_unet(**ref_shim.unet_kwargs(model_channels))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth.seeded_state_dict(shapes, seed)
+    net.load_state_dict(sd, strict=True)
+    return net, shapes
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    c = ref_shim.ref_classes()
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+
+    # ---------------------------------------------------------------- scalar KATs
+    disc = c["discretizer"].EDMDiscretization(sigma_min=0.002, sigma_max=700.0, rho=7.0)
+    scal = c["denoiser_scaling"].VScalingWithEDMcNoise()
+    g = c["guiders"]
+    kat = {
+        "edm_sigmas_10": disc(10).tolist(),
+        "edm_sigmas_50": disc(50).tolist(),
+        "edm_sigmas_7_noappend": disc(7, do_append_zero=False).tolist(),
+        "vscaling": {str(s): [float(v) for v in scal(torch.tensor(float(s)))] for s in (700.0, 1.0, 0.002, 13.37)},
+        "x0_scale": float(torch.sqrt(1.0 + disc(50)[0] ** 2)),
+        "linear_guider_25": g.LinearPredictionGuider(num_frames=25, max_scale=2.5, min_scale=1.0).scale[0].tolist(),
+        "triangle_guider_25": g.TrianglePredictionGuider(num_frames=25, max_scale=2.5, min_scale=1.0).scale[0].tolist(),
+        "timestep_embedding_320": c["util"].timestep_embedding(torch.tensor([0.25 * float(torch.tensor(700.0).log()), 0.0, 3.0]), 320).tolist(),
+    }
+    with open(os.path.join(GOLD, "kat.json"), "w") as f:
+        json.dump(kat, f)
+    print("kat.json written")
+
+    # ---------------------------------------------------------------- tiny UNet forwards
+    t0 = time.time()
+    net, shapes = seeded_ref_unet(64, seed=0)
+    digest = synth.shapes_digest(shapes)
+    for T, tag, sigma in ((5, "t5", 3.7), (25, "t25", 41.0)):
+        x8, ts, ctx, y, mask = unet_inputs(T, 16, 32, seed=11, sigma=sigma)
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=T)
+        torch.save({"out": out.clone(), "sigma": sigma, "T": T, "H": 16, "W": 32, "seed_w": 0, "seed_x": 11, "digest": digest,
+                    "model_channels": 64}, os.path.join(GOLD, f"unet_tiny_{tag}.pt"))
+        print(f"unet_tiny_{tag}: out rms {out.pow(2).mean().sqrt():.4f} absmax {out.abs().max():.4f}  ({time.time()-t0:.1f}s)")
+
+    # ---------------------------------------------------------------- denoiser + sampler (3 steps, T=5)
+    T, H, W = 5, 16, 32
+    w = synth.window_inputs(T=T, H=H, W=W, seed=21, n_cond=1, trajectory=[0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2])
+    wrapper = c["OpenAIWrapper"](net)
+    den = c["Denoiser"](scaling_config={"target": CFG + "denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
+
+    def denoiser(x, sigma, cond, cond_mask):
+        return den(wrapper, x, sigma, cond, cond_mask)
+
+    disc_cfg = {"target": CFG + "discretizer.EDMDiscretization", "params": {"sigma_min": 0.002, "sigma_max": 700.0, "rho": 7.0}}
+    res = {"T": T, "H": H, "W": W, "seed_w": 0, "seed_x": 21, "digest": digest, "steps": 3}
+    guiders = {
+        "vanilla": {"target": CFG + "guiders.VanillaCFG", "params": {"scale": 2.5}},
+        "linear": {"target": CFG + "guiders.LinearPredictionGuider", "params": {"num_frames": T, "max_scale": 2.5, "min_scale": 1.0}},
+        "triangle": {"target": CFG + "guiders.TrianglePredictionGuider", "params": {"num_frames": T, "max_scale": 2.5, "min_scale": 1.0}},
+        "identity": {"target": CFG + "guiders.IdentityGuider"},
+    }
+    for name, gcfg in guiders.items():
+        sampler = c["EulerEDMSampler"](num_steps=3, discretization_config=disc_cfg, guider_config=gcfg, s_churn=0.0, s_tmin=0.0,
+                                       s_tmax=999.0, s_noise=1.0, verbose=False, device="cpu")
+        noise = w["noise"].clone()
+        cc = {k: v.clone() for k, v in w["c"].items()}
+        ucc = {k: v.clone() for k, v in w["uc"].items()}
+        out = sampler(denoiser, noise, cond=cc, uc=ucc, cond_frame=w["cond_frame"], cond_mask=w["cond_mask"])
+        res[name] = out.clone()
+        res[name + "_noise_after"] = noise.clone()  # the reference scales the caller's tensor in place (sampling.py:36)
+        print(f"sampler {name}: rms {out.pow(2).mean().sqrt():.4f}")
+    # one plain Denoiser.forward for the boundary test
+    sig = torch.full((2 * T,), 5.0)
+    x2, s2, c2, m2 = g.VanillaCFG(2.5).prepare_inputs(w["noise"] * 5.0, sig[:T], w["c"], w["cond_mask"], w["uc"])
+    res["denoiser_out"] = denoiser(x2, s2, c2, m2).clone()
+    torch.save(res, os.path.join(GOLD, "sampler_tiny.pt"))
+    del net, wrapper
+
+    # ---------------------------------------------------------------- the shipped 1.65 B configuration
+    if "--full" in sys.argv:
+        t0 = time.time()
+        net, shapes = seeded_ref_unet(320, seed=0)
+        print(f"full UNet built+seeded in {time.time()-t0:.0f}s, {sum(int(torch.tensor(s).prod()) for s in shapes.values())/1e9:.3f} B params")
+        T = 5
+        x8, ts, ctx, y, mask = unet_inputs(T, 16, 32, seed=31, sigma=9.0)
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=T)
+        torch.save({"out": out.clone(), "sigma": 9.0, "T": T, "H": 16, "W": 32, "seed_w": 0, "seed_x": 31,
+                    "digest": synth.shapes_digest(shapes), "model_channels": 320}, os.path.join(GOLD, "unet_full_t5.pt"))
+        print(f"unet_full_t5: out rms {out.pow(2).mean().sqrt():.4f} absmax {out.abs().max():.4f} forward {time.time()-t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main()

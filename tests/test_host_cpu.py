@@ -1,0 +1,145 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the host logic (schedules, guiders,
+scalings, config plumbing, state-dict contract) matches the reference's known answers, and the product path refuses to
+compute on the CPU (no fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_abi_header_table_and_library_agree():
+    from vista_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vista_hip.h")).read()
+    declared = set(re.findall(r"^\s*int\s+(vk_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no entry points parsed from include/vista_hip.h"
+    assert declared == set(_lib.SIGNATURES), f"header vs ctypes table: {declared ^ set(_lib.SIGNATURES)}"
+    assert os.path.exists(_lib.LIB_PATH), "libvista_hip.so not built (python -m vista_amd.build)"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} missing from libvista_hip.so"
+    assert _lib.load().vk_abi_version() == 1
+
+
+def test_gemm_desc_layout_matches_header():
+    """Field order of the ctypes mirror must follow the C struct (a silent mismatch would corrupt every GEMM launch)."""
+    from vista_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vista_hip.h")).read()
+    start = hdr.index("typedef struct VkGemmDesc {") + len("typedef struct VkGemmDesc {")
+    body = hdr[start:hdr.index("} VkGemmDesc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef"):
+            continue
+        decl = re.sub(r"^(const\s+)?(void|float|int32_t)\s*\*?", "", decl).strip()
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert names == [f[0] for f in _lib.VkGemmDesc._fields_], names
+
+
+def test_schedules_guiders_scalings_match_reference_kats():
+    from vista_amd.modules.diffusionmodules import denoiser_scaling, discretizer, guiders
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))
+    disc = discretizer.EDMDiscretization(sigma_min=0.002, sigma_max=700.0, rho=7.0)
+    for n in (10, 50):
+        assert torch.equal(disc(n), torch.tensor(kat[f"edm_sigmas_{n}"])), "sigma schedule must be bit-identical to the reference's"
+    assert torch.equal(disc(7, do_append_zero=False), torch.tensor(kat["edm_sigmas_7_noappend"]))
+    assert torch.equal(disc(5, flip=True), torch.flip(disc(5), (0,)))
+    scal = denoiser_scaling.VScalingWithEDMcNoise()
+    for s, ref in kat["vscaling"].items():
+        got = torch.tensor([float(v) for v in scal(torch.tensor(float(s)))])
+        assert torch.allclose(got, torch.tensor(ref), rtol=1e-6, atol=1e-9)
+    lin = guiders.LinearPredictionGuider(num_frames=25, max_scale=2.5, min_scale=1.0)
+    tri = guiders.TrianglePredictionGuider(num_frames=25, max_scale=2.5, min_scale=1.0)
+    assert torch.allclose(lin.scale[0], torch.tensor(kat["linear_guider_25"]))
+    assert torch.allclose(tri.scale[0], torch.tensor(kat["triangle_guider_25"]), atol=1e-6)
+    assert torch.allclose(guiders.VanillaCFG(2.5).frame_scales(25), torch.full((25,), 2.5))
+    assert guiders.IdentityGuider().frame_scales(25) is None
+
+
+def test_guider_prepare_inputs_layout():
+    from vista_amd.modules.diffusionmodules import guiders
+    x, s, m = torch.randn(3, 4, 2, 2), torch.ones(3), torch.tensor([1.0, 0, 0])
+    c = {"vector": torch.randn(3, 8), "crossattn": torch.randn(3, 1, 16), "concat": torch.randn(3, 4, 2, 2)}
+    uc = {k: torch.zeros_like(v) for k, v in c.items()}
+    x2, s2, c2, m2 = guiders.VanillaCFG(2.5).prepare_inputs(x, s, c, m, uc)
+    assert x2.shape[0] == 6 and torch.equal(x2[:3], x) and torch.equal(x2[3:], x)
+    for k in c:  # the uncond half comes FIRST (guiders.py:32)
+        assert torch.equal(c2[k][:3], uc[k]) and torch.equal(c2[k][3:], c[k])
+    assert torch.equal(m2, torch.cat([m, m])) and torch.equal(s2, torch.cat([s, s]))
+    xi, si, ci, mi = guiders.IdentityGuider().prepare_inputs(x, s, c, m, uc)
+    assert xi is x and mi is m
+
+
+def test_instantiate_from_config_maps_reference_targets():
+    from vista_amd.modules.diffusionmodules import discretizer, guiders, sampling
+    from vista_amd.util import append_dims, instantiate_from_config
+    g = instantiate_from_config({"target": "vwm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 2.5}})
+    assert isinstance(g, guiders.VanillaCFG)
+    s = sampling.EulerEDMSampler(num_steps=10, discretization_config={"target": "vwm.modules.diffusionmodules.discretizer.EDMDiscretization",
+                                                                      "params": {"sigma_min": 0.002, "sigma_max": 700.0, "rho": 7.0}},
+                                 guider_config={"target": "vwm.modules.diffusionmodules.guiders.TrianglePredictionGuider",
+                                                "params": {"num_frames": 25, "max_scale": 2.5, "min_scale": 1.0}},
+                                 s_churn=0.0, s_tmin=0.0, s_tmax=999.0, s_noise=1.0, verbose=False, device="cuda")
+    assert isinstance(s.discretization, discretizer.EDMDiscretization) and isinstance(s.guider, guiders.TrianglePredictionGuider)
+    assert len(s.host_sigmas()) == 11 and s.host_sigmas()[-1] == 0
+    with pytest.raises(KeyError):
+        instantiate_from_config({"params": {}})
+    with pytest.raises(ValueError):
+        append_dims(torch.zeros(2, 2), 1)
+
+
+def test_state_dict_contract_matches_reference():
+    """Names and shapes of every VideoUNet tensor equal the reference's (digest recorded from the real VideoUNet)."""
+    from vista_amd import synth
+    from vista_amd.config import unet_kwargs
+    from vista_amd.modules.diffusionmodules.video_model import VideoUNet
+    g = torch.load(os.path.join(GOLD, "unet_tiny_t5.pt"))
+    net = VideoUNet(**unet_kwargs(64))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert len(shapes) == 1496 and synth.shapes_digest(shapes) == g["digest"]
+    for k in ("time_embed.0.weight", "input_blocks.0.0.weight", "input_blocks.1.0.time_stack.in_layers.2.weight",
+              "input_blocks.1.1.transformer_blocks.0.attn2.k_adapter_action_control.weight", "input_blocks.3.0.op.weight",
+              "middle_block.1.time_stack.0.ff_in.net.0.proj.weight", "output_blocks.2.1.conv.weight", "output_blocks.5.2.conv.weight",
+              "input_blocks.1.0.time_mixer.mix_factor", "input_blocks.1.1.time_pos_embed.2.bias", "out.2.weight", "label_emb.0.2.bias"):
+        assert k in shapes, k
+    # unexpected / missing keys surface through load_state_dict(strict=True)
+    sd = synth.seeded_state_dict(shapes, 0)
+    net.load_state_dict(sd, strict=True)
+    sd.pop("out.2.weight")
+    with pytest.raises(RuntimeError):
+        net.load_state_dict(sd, strict=True)
+
+
+def test_seeded_tensors_are_reproducible_and_nonzero():
+    from vista_amd import synth
+    a = synth.seeded_tensor("input_blocks.1.0.out_layers.3.weight", (64, 64, 3, 3), 0)
+    b = synth.seeded_tensor("input_blocks.1.0.out_layers.3.weight", (64, 64, 3, 3), 0)
+    assert torch.equal(a, b) and a.abs().max() > 0
+    assert not torch.equal(a, synth.seeded_tensor("input_blocks.1.0.out_layers.3.weight", (64, 64, 3, 3), 1))
+    w = synth.window_inputs(T=5, H=4, W=8, seed=3, trajectory=[0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2])
+    assert w["c"]["crossattn"].shape == (5, 1, 3456) and w["c"]["vector"].shape == (5, 768) and w["c"]["concat"].shape == (5, 4, 4, 8)
+    assert w["uc"]["crossattn"].abs().max() == 0 and torch.equal(w["uc"]["vector"], w["c"]["vector"])
+    assert w["cond_mask"].tolist() == [1, 0, 0, 0, 0]
+
+
+def test_product_path_refuses_cpu():
+    from vista_amd import ops
+    from vista_amd._lib import VistaHipError
+    from vista_amd.config import unet_kwargs
+    from vista_amd.modules.diffusionmodules.video_model import VideoUNet
+    with pytest.raises(VistaHipError):
+        ops.layernorm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.ones(64), torch.zeros(64))
+    net = VideoUNet(**unet_kwargs(64))
+    with pytest.raises(VistaHipError):
+        net(torch.zeros(2, 8, 16, 32), timesteps=torch.zeros(2), context=torch.zeros(2, 1, 3456), y=torch.zeros(2, 768),
+            cond_mask=torch.zeros(2), num_frames=2)
+    # parameter containers carry no eager arithmetic
+    with pytest.raises(RuntimeError):
+        net.time_embed[0](torch.zeros(1, 64))

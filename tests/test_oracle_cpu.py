@@ -1,0 +1,105 @@
+"""Pins the CPU oracle (oracle/vista_oracle.py) against the golden vectors produced by the REAL reference
+(oracle/make_golden.py -> tests/golden/) and, where /root/reference is mounted, against the live reference modules.
+fp32 on both sides: tolerance 2e-4 of the output rms (summation-order noise only)."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import ref_shim, vista_oracle as O
+from oracle.make_golden import unet_inputs
+from vista_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _rel(a, b):
+    return ((a - b).abs().max() / b.pow(2).mean().sqrt()).item()
+
+
+def test_scalar_kats():
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))
+    for n in (10, 50):
+        assert torch.allclose(O.edm_sigmas(n), torch.tensor(kat[f"edm_sigmas_{n}"]), rtol=1e-6, atol=0)
+    assert torch.allclose(O.edm_sigmas(7, append_zero=False), torch.tensor(kat["edm_sigmas_7_noappend"]), rtol=1e-6)
+    # the values quoted in SURVEY.md 8c
+    s10 = O.edm_sigmas(10)
+    assert abs(s10[0].item() - 700.00012) < 1e-3 and abs(s10[1].item() - 352.99237) < 1e-3 and s10[-1].item() == 0.0
+    for s, ref in kat["vscaling"].items():
+        got = [float(v) for v in O.vscaling_edm_cnoise(torch.tensor(float(s)))]
+        assert torch.allclose(torch.tensor(got), torch.tensor(ref), rtol=1e-6, atol=1e-9), s
+    assert torch.allclose(O.linear_guider_scale(25), torch.tensor(kat["linear_guider_25"]))
+    assert torch.allclose(O.triangle_guider_scale(25), torch.tensor(kat["triangle_guider_25"]), atol=1e-6)
+    tri = O.triangle_guider_scale(25)
+    assert abs(tri[0].item() - 1.0) < 1e-6 and abs(tri[12].item() - 2.5) < 1e-6 and abs(tri[1].item() - 1.125) < 1e-6
+    te = O.timestep_embedding(torch.tensor([0.25 * float(torch.tensor(700.0).log()), 0.0, 3.0]), 320)
+    assert torch.allclose(te, torch.tensor(kat["timestep_embedding_320"]), atol=1e-6)
+    assert abs(kat["x0_scale"] - 700.00073) < 1e-3
+
+
+def _tiny_sd(model_channels=64):
+    from vista_amd.modules.diffusionmodules.video_model import VideoUNet
+    from vista_amd.config import unet_kwargs
+    net = VideoUNet(**unet_kwargs(model_channels))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    return synth.seeded_state_dict(shapes, 0), shapes
+
+
+@pytest.mark.parametrize("tag", ["t5", "t25"])
+def test_oracle_unet_matches_reference_golden(tag):
+    g = torch.load(os.path.join(GOLD, f"unet_tiny_{tag}.pt"))
+    sd, shapes = _tiny_sd()
+    assert synth.shapes_digest(shapes) == g["digest"], "state-dict names/shapes drifted from the reference VideoUNet"
+    x8, ts, ctx, y, mask = unet_inputs(g["T"], g["H"], g["W"], seed=g["seed_x"], sigma=g["sigma"])
+    with torch.no_grad():
+        out = O.unet_forward(sd, x8, ts, ctx, y, mask, g["T"])
+    assert _rel(out, g["out"]) < 2e-4
+
+
+def test_oracle_sampler_matches_reference_golden():
+    g = torch.load(os.path.join(GOLD, "sampler_tiny.pt"))
+    sd, _ = _tiny_sd()
+    T, H, W = g["T"], g["H"], g["W"]
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1, trajectory=[0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2])
+
+    def denoise(x, sigma, cond, cond_mask):
+        return O.denoiser_forward(sd, x, sigma, cond, cond_mask, T)
+
+    with torch.no_grad():
+        for name, scale, guider in (("vanilla", 2.5, "cfg"), ("linear", O.linear_guider_scale(T), "cfg"),
+                                    ("triangle", O.triangle_guider_scale(T), "cfg"), ("identity", None, "identity")):
+            out = O.euler_edm_sample(denoise, w["noise"], w["c"], w["uc"], w["cond_frame"], w["cond_mask"], 3, scale=scale, guider=guider)
+            assert _rel(out, g[name]) < 5e-4, name
+        sig = torch.full((T,), 5.0)
+        x2, s2, c2, m2 = O.guider_prepare_inputs(w["noise"] * 5.0, sig, w["c"], w["cond_mask"], w["uc"])
+        assert _rel(denoise(x2, s2, c2, m2), g["denoiser_out"]) < 2e-4
+    assert torch.allclose(g["vanilla_noise_after"], w["noise"] * torch.sqrt(1.0 + O.edm_sigmas(3)[0] ** 2))
+
+
+@pytest.mark.skipif(not ref_shim.available(), reason="reference tree not mounted (GPU box)")
+def test_oracle_matches_live_reference_block():
+    """Live check of one full-width transformer + resblock pair against the reference modules themselves."""
+    import contextlib
+    import io
+    ref_shim.install()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from vwm.modules.diffusionmodules.video_model import VideoResBlock
+        from vwm.modules.video_attention import SpatialVideoTransformer
+        rb = VideoResBlock(channels=320, emb_channels=1280, dropout=0.0, out_channels=640, video_kernel_size=[3, 1, 1],
+                           merge_strategy="learned_with_images").eval()
+        st = SpatialVideoTransformer(320, 5, 64, depth=1, context_dim=1024, use_linear=True, use_spatial_context=True, ff_in=True,
+                                     merge_strategy="learned_with_images", attn_mode="softmax-xformers", action_control=True).eval()
+    T, n, hh, ww = 3, 6, 4, 8
+    x = torch.randn(n, 320, hh, ww)
+    emb = torch.randn(n, 1280)
+    ctx = torch.randn(n, 1, synth.CTX_DIM)
+    with torch.no_grad():
+        for mod, name in ((rb, "rb"), (st, "st")):
+            sd = synth.seeded_state_dict({k: tuple(v.shape) for k, v in mod.state_dict().items()}, 3)
+            mod.load_state_dict(sd)
+            sdp = {f"{name}.{k}": v for k, v in sd.items()}
+            if name == "rb":
+                assert _rel(O.video_resblock(sdp, "rb", x, emb, T), mod(x, emb, T)) < 2e-4
+            else:
+                assert _rel(O.spatial_video_transformer(sdp, "st", x, ctx, T, True), mod(x, ctx, None, T)) < 2e-4

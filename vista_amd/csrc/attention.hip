@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
             const int key = key0 + lr + 32 * i;
             rk[i] = (key < S) ? *(const uint4*)(kbase + (size_t)key * ldk) : make_uint4(0, 0, 0, 0);
             const int kk = key0 + lc * 8;
-            rv[i] = (kk < S) ? *(const uint4*)(vbase + (size_t)(lr + 32 * i) * S + kk) : make_uint4(0, 0, 0, 0);
+            rv[i] = (kk < S) ? *(const uint4*)(vbase + (size_t)(lr + 32 * i) * S + key0) : make_uint4(0, 0, 0, 0);  // vbase already has +lc*8
         }
     };
     auto store_tile = [&](int stage) {

@@ -1,0 +1,197 @@
+"""Spatial transformer of the VideoUNet (reference: vwm/modules/attention.py), MI355X-native.
+
+Same classes, constructor arguments and state-dict names as the reference; `forward` works on token-major bf16
+activations ((n_img*S, C), C contiguous) and runs entirely on the HIP kernels of libvista_hip.so:
+
+  BasicTransformerBlock (attention.py:514-524)
+      x += to_out(softmax(q k^T/8) v)        LN -> fused [q|k] GEMM + V^T GEMM -> vk_attn_spatial_bf16 -> out GEMM(+res)
+      x += attn2(norm2(x), context)          context is ONE token (CLIP (+) action embeddings), so softmax == 1 and the
+                                             output is to_out(to_v(ctx) + v_adapter(ctx_act)) for every query
+                                             (attention.py:341-353,400-421): computed per image by two tiny GEMMs and
+                                             added as a per-image row vector in the attn1 out-projection epilogue.
+                                             Bit-for-bit the same function of the inputs; q/k/norm2 weights cannot
+                                             influence the result and are kept only for state-dict compatibility.
+      x += FF(norm3(x))                      LN -> GEGLU GEMM (value*gelu(gate) fused in the epilogue) -> out GEMM(+res)
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .diffusionmodules.util import Dropout, LayerNorm, Linear, NormParams, zero_module
+
+
+def exists(val):
+    return val is not None
+
+
+def default(val, d):
+    return val if exists(val) else (d() if callable(d) else d)
+
+
+class Packable:
+    """Lazy bf16 weight packing (ops.pack_*), rebuilt when parameters move device or are reloaded."""
+    _pk = None
+    _pk_dev = None
+
+    def packed(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise ops._lib.VistaHipError(f"{self.__class__.__name__}: parameters are on {dev}; move the model to the MI355X "
+                                         "(.cuda()) -- vista_amd has no CPU path")
+        if self._pk is None or self._pk_dev != dev:
+            with torch.no_grad():
+                self._pk = self._pack(dev)
+            self._pk_dev = dev
+        return self._pk
+
+    def invalidate_packed(self):
+        self._pk = None
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(nn.Module, Packable):
+    """attention.py:95-128 (glu=True on this path). net = [GEGLU, Dropout, Linear] -> keys net.0.proj.*, net.2.*"""
+
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.0, zero_init=False):
+        super().__init__()
+        if not glu:
+            raise NotImplementedError("non-gated FeedForward is not on the Vista inference path")
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        self.net = nn.Sequential(GEGLU(dim, inner_dim), Dropout(dropout), Linear(inner_dim, dim_out))
+        if zero_init:
+            zero_module(self.net[-1])
+
+    def _pack(self, dev):
+        return {"in": ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev),
+                "out": ops.pack_linear(self.net[2].weight, self.net[2].bias, dev)}
+
+    def forward(self, y, **epilogue):
+        """y: LN output (M, dim). Returns net(y) fused with the residual / blend epilogue given by the caller."""
+        pk = self.packed()
+        return ops.linear(ops.linear(y, pk["in"]), pk["out"], **epilogue)
+
+
+class MemoryEfficientCrossAttention(nn.Module, Packable):
+    """attention.py:246-421. Parameter names identical; LoRA branches are inference-off (`add_lora: False`,
+    vista.yaml:39; merged offline by bin_to_st.py) and rejected here."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0, zero_init=False, causal=False,
+                 add_lora=False, lora_rank=16, lora_scale=1.0, action_control=False, **kwargs):
+        super().__init__()
+        if add_lora:
+            raise NotImplementedError("add_lora=True is a training-time option; merge LoRA weights offline (bin_to_st.py)")
+        if causal:
+            raise NotImplementedError("causal attention is not used by Vista")
+        if dim_head != 64:
+            raise NotImplementedError("the gfx950 attention kernels are specialised for head dim 64 (num_head_channels: 64)")
+        inner_dim = dim_head * heads
+        self.is_self = context_dim is None
+        context_dim = default(context_dim, query_dim)
+        self.heads, self.dim_head, self.inner_dim, self.query_dim = heads, dim_head, inner_dim, query_dim
+        self.to_q = Linear(query_dim, inner_dim, bias=False)
+        self.to_k = Linear(context_dim, inner_dim, bias=False)
+        self.to_v = Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(Linear(inner_dim, query_dim), Dropout(dropout))
+        if zero_init:
+            zero_module(self.to_out[0])
+        self.add_lora = False
+        self.action_control = action_control
+        self.context_dim = context_dim
+        if action_control:
+            self.k_adapter_action_control = zero_module(Linear(128 * 19, inner_dim, bias=False))
+            self.v_adapter_action_control = zero_module(Linear(128 * 19, inner_dim, bias=False))
+
+    def _pack(self, dev):
+        pk = {"out": ops.pack_linear(self.to_out[0].weight, self.to_out[0].bias, dev)}
+        if self.is_self and getattr(self, "temporal", False):  # per-pixel attention over frames: one fused q|k|v GEMM
+            pk["qkv"] = ops.pack_linear_cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dev)
+        elif self.is_self:  # spatial: fused q|k GEMM + a transposed-output V^T GEMM
+            pk["qk"] = ops.pack_linear_cat([self.to_q.weight, self.to_k.weight], dev)
+            pk["v"] = ops.pack_linear(self.to_v.weight, None, dev)
+        else:
+            ws = [self.to_v.weight]
+            if self.action_control:
+                ws.append(self.v_adapter_action_control.weight)
+            pk["vctx"] = ops.pack_linear(torch.cat([w.detach().float() for w in ws], 1), None, dev)  # [to_v | v_adapter] along K
+        return pk
+
+    def context_vector(self, ctx):
+        """Cross-attention against a ONE-token context: returns to_out(v(ctx)) as (n_ctx, query_dim) f32.
+        ctx: (n_ctx, context_dim [+ 2432]) bf16."""
+        pk = self.packed()
+        if ctx.shape[-1] != pk["vctx"].K:
+            raise ValueError(f"context width {ctx.shape[-1]} does not match to_v (+ action adapter) width {pk['vctx'].K}")
+        v = ops.linear(ctx, pk["vctx"])
+        return ops.linear(v, pk["out"], out_f32=True)
+
+
+class BasicTransformerBlock(nn.Module, Packable):
+    ATTENTION_MODES = {"softmax": MemoryEfficientCrossAttention, "softmax-xformers": MemoryEfficientCrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, use_checkpoint=False,
+                 disable_self_attn=False, attn_mode="softmax", sdp_backend=None, add_lora=False, action_control=False):
+        super().__init__()
+        assert attn_mode in self.ATTENTION_MODES
+        if disable_self_attn:
+            raise NotImplementedError("disable_self_attn is not used by Vista")
+        attn_cls = self.ATTENTION_MODES[attn_mode]
+        self.disable_self_attn = False
+        self.attn1 = attn_cls(query_dim=dim, context_dim=None, heads=n_heads, dim_head=d_head, dropout=dropout, add_lora=add_lora)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                              add_lora=add_lora, action_control=action_control)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
+        self.norm3 = LayerNorm(dim)
+        self.use_checkpoint = use_checkpoint
+        self.n_heads, self.dim = n_heads, dim
+
+    def forward(self, x, context, n_img, S):
+        """x: (n_img*S, dim) bf16 tokens; context: (n_img, ctx_width) bf16 (one context token per image)."""
+        a1 = self.attn1.packed()
+        C = self.dim
+        y = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qk = ops.linear(y, a1["qk"])
+        vt = ops.linear_vt(y, a1["v"], S)
+        att = ops.attn_spatial(qk[:, :C], qk[:, C:], vt, n_img, self.n_heads, S, self.attn1.dim_head ** -0.5)
+        cv = self.attn2.context_vector(context)  # attn2(norm2(x), context): constant over the image's tokens
+        x = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=S)
+        y = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self.ff(y, res1=x)
+
+
+class SpatialTransformer(nn.Module, Packable):
+    """attention.py:527-632 with use_linear=True (the Vista setting). Parameter layout only; the video subclass
+    (video_attention.SpatialVideoTransformer) implements forward."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None, disable_self_attn=False,
+                 use_linear=False, attn_type="softmax", use_checkpoint=False, sdp_backend=None, add_lora=False,
+                 action_control=False):
+        super().__init__()
+        if not use_linear:
+            raise NotImplementedError("use_linear_in_transformer=False (1x1 conv projections) is not the Vista configuration")
+        if exists(context_dim) and not isinstance(context_dim, (list, tuple)):
+            context_dim = [context_dim]
+        if exists(context_dim) and isinstance(context_dim, (list, tuple)):
+            context_dim = list(context_dim)
+            if depth != len(context_dim):
+                assert all(c == context_dim[0] for c in context_dim), "Need homogenous context_dim to match depth automatically"
+                context_dim = depth * [context_dim[0]]
+        elif context_dim is None:
+            context_dim = [None] * depth
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.norm = NormParams(in_channels, 1e-6, 32)  # Normalize(): GroupNorm(32, eps=1e-6), attention.py:141-142
+        self.proj_in = Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim[d],
+                                  disable_self_attn=disable_self_attn, attn_mode=attn_type, use_checkpoint=use_checkpoint,
+                                  add_lora=add_lora, action_control=action_control) for d in range(depth)])
+        self.proj_out = zero_module(Linear(inner_dim, in_channels))
+        self.use_linear = use_linear

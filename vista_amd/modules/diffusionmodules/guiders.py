@@ -1,0 +1,102 @@
+"""Classifier-free-guidance batching and combination (reference: vwm/modules/diffusionmodules/guiders.py).
+`prepare_inputs` is pure tensor plumbing (cat); the combine runs as one HIP kernel (vk_cfg_combine)."""
+from abc import ABC, abstractmethod
+from typing import List, Literal, Optional, Union
+
+import torch
+
+from ... import ops
+from ...util import default
+
+
+class Guider(ABC):
+    @abstractmethod
+    def __call__(self, x: torch.Tensor, sigma: float) -> torch.Tensor:
+        pass
+
+    def prepare_inputs(self, x, s, c, cond_mask, uc):
+        pass
+
+    def frame_scales(self, num_frames):
+        """Per-frame guidance scale (T,) f32 on the host; None = no CFG doubling (IdentityGuider)."""
+        return None
+
+
+def _cfg_prepare(x, s, c, cond_mask, uc, keys):
+    c_out = dict()
+    for k in c:
+        if k in keys:
+            c_out[k] = torch.cat((uc[k], c[k]), 0)
+        else:
+            assert c[k] == uc[k]
+            c_out[k] = c[k]
+    return torch.cat([x] * 2), torch.cat([s] * 2), c_out, torch.cat([cond_mask] * 2)
+
+
+class VanillaCFG(Guider):
+    def __init__(self, scale: float):
+        self.scale = scale
+
+    def frame_scales(self, num_frames):
+        return torch.full((num_frames,), float(self.scale))
+
+    def __call__(self, x, sigma):
+        n = x.shape[0] // 2
+        return ops.cfg_combine(x.float(), torch.full((n,), float(self.scale), device=x.device))
+
+    def prepare_inputs(self, x, s, c, cond_mask, uc):
+        return _cfg_prepare(x, s, c, cond_mask, uc, ["vector", "crossattn", "concat"])
+
+
+class IdentityGuider(Guider):
+    def __call__(self, x, sigma):
+        return x
+
+    def prepare_inputs(self, x, s, c, cond_mask, uc):
+        return x, s, {k: c[k] for k in c}, cond_mask
+
+
+class LinearPredictionGuider(Guider):
+    def __init__(self, num_frames: int = 25, max_scale: float = 2.5, min_scale: float = 1.0,
+                 additional_cond_keys: Optional[Union[List[str], str]] = None):
+        self.min_scale, self.max_scale, self.num_frames = min_scale, max_scale, num_frames
+        self.scale = torch.linspace(min_scale, max_scale, num_frames).unsqueeze(0)
+        additional_cond_keys = default(additional_cond_keys, list())
+        if isinstance(additional_cond_keys, str):
+            additional_cond_keys = [additional_cond_keys]
+        self.additional_cond_keys = additional_cond_keys
+
+    def frame_scales(self, num_frames):
+        assert num_frames == self.num_frames
+        return self.scale[0].clone()
+
+    def __call__(self, x, sigma):
+        n = x.shape[0] // 2
+        b = n // self.num_frames
+        return ops.cfg_combine(x.float(), self.scale[0].repeat(b).to(x.device))
+
+    def prepare_inputs(self, x, s, c, cond_mask, uc):
+        return _cfg_prepare(x, s, c, cond_mask, uc, ["vector", "crossattn", "concat"] + self.additional_cond_keys)
+
+
+class TrianglePredictionGuider(LinearPredictionGuider):
+    def __init__(self, num_frames: int = 25, max_scale: float = 2.5, min_scale: float = 1.0, period: float = 1.0,
+                 period_fusing: Literal["mean", "multiply", "max"] = "max",
+                 additional_cond_keys: Optional[Union[List[str], str]] = None):
+        super().__init__(num_frames, max_scale, min_scale, additional_cond_keys)
+        values = torch.linspace(0, 1, num_frames)
+        if isinstance(period, float):
+            period = [period]
+        scales = [self.triangle_wave(values, p) for p in period]
+        if period_fusing == "mean":
+            scale = sum(scales) / len(period)
+        elif period_fusing == "multiply":
+            scale = torch.prod(torch.stack(scales), dim=0)
+        elif period_fusing == "max":
+            scale = torch.max(torch.stack(scales), dim=0).values
+        else:
+            raise NotImplementedError
+        self.scale = (scale * (max_scale - min_scale) + min_scale).unsqueeze(0)
+
+    def triangle_wave(self, values, period):
+        return 2 * (values / period - torch.floor(values / period + 0.5)).abs()

@@ -1,0 +1,147 @@
+"""UNet primitives (reference: vwm/modules/diffusionmodules/openaimodel.py), MI355X-native.
+
+  ResBlock._forward (openaimodel.py:258-284):
+      h = conv(silu(GN32(x)))          vk_groupnorm_silu_bf16 -> implicit-GEMM 3x3 (or 3x1x1) conv
+      h += Linear(silu(emb))[n]        per-image row vector added in that conv's epilogue
+      h = conv(silu(GN32(h)))          second conv; `skip(x) + h` is its residual epilogue
+  Upsample (openaimodel.py:86-103): nearest x2 fused into the conv's gather; Downsample (:136): stride-2 gather.
+"""
+from typing import Iterable, Optional
+
+import torch.nn as nn
+
+from ... import ops
+from ..attention import Packable
+from .util import Dropout, SiLU, conv_nd, linear, normalization, timestep_embedding, zero_module
+
+
+class TimestepBlock(nn.Module):
+    """Any module where forward() takes timestep embeddings as a second argument."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """openaimodel.py:27-53: passes (emb | context | num_frames) to the children that take them.
+    Activations are token-major: x (n_img, S, C) bf16 with the spatial size (H, W) carried alongside."""
+
+    def forward(self, x, emb_silu, context=None, frame_idx=None, num_frames=None, H=None, W=None):
+        from ..video_attention import SpatialVideoTransformer
+        from .video_model import VideoResBlock
+        for layer in self:
+            if isinstance(layer, VideoResBlock):
+                x = layer(x, emb_silu, num_frames, H, W)
+            elif isinstance(layer, SpatialVideoTransformer):
+                x = layer(x, context, frame_idx, num_frames, H, W)
+            elif isinstance(layer, (Upsample, Downsample)):
+                x, H, W = layer(x, H, W)
+            else:
+                raise TypeError(f"unexpected layer {type(layer).__name__} in TimestepEmbedSequential")
+        return x, H, W
+
+
+class Upsample(nn.Module, Packable):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_up=False, kernel_size=3, scale_factor=2):
+        super().__init__()
+        if dims != 2 or not use_conv or kernel_size != 3 or scale_factor != 2 or padding != 1:
+            raise NotImplementedError("Vista uses Upsample(dims=2, use_conv=True, k=3, x2)")
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv, self.dims = use_conv, dims
+        self.conv = conv_nd(dims, self.channels, self.out_channels, kernel_size, padding=padding)
+
+    def _pack(self, dev):
+        return ops.pack_conv3x3(self.conv.weight, self.conv.bias, device=dev)
+
+    def forward(self, x, H, W):
+        assert x.shape[-1] == self.channels
+        out, Ho, Wo = ops.conv3x3(x, self.packed(), x.shape[0], H, W, ups=2)
+        return out, Ho, Wo
+
+
+class Downsample(nn.Module, Packable):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_down=False):
+        super().__init__()
+        if dims != 2 or not use_conv or padding != 1:
+            raise NotImplementedError("Vista uses Downsample(dims=2, use_conv=True)")
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv, self.dims = use_conv, dims
+        self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def _pack(self, dev):
+        return ops.pack_conv3x3(self.op.weight, self.op.bias, device=dev)
+
+    def forward(self, x, H, W):
+        assert x.shape[-1] == self.channels
+        out, Ho, Wo = ops.conv3x3(x, self.packed(), x.shape[0], H, W, stride=2)
+        return out, Ho, Wo
+
+
+class ResBlock(TimestepBlock, Packable):
+    """openaimodel.py:146-284. dims=2: 3x3 convs; dims=3 with kernel (3,1,1): the temporal `time_stack`."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False, dims=2,
+                 use_checkpoint=False, up=False, down=False, kernel_size=3, exchange_temb_dims=False, skip_t_emb=False, causal=False):
+        super().__init__()
+        if up or down or use_scale_shift_norm or skip_t_emb or use_conv or causal:
+            raise NotImplementedError("resblock_updown / scale-shift norm / skip_t_emb / causal are not used by Vista")
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_checkpoint = use_checkpoint
+        self.exchange_temb_dims = exchange_temb_dims
+        self.dims = dims
+        if isinstance(kernel_size, Iterable):
+            kernel_size = tuple(kernel_size)
+            padding = [k // 2 for k in kernel_size]
+        else:
+            padding = kernel_size // 2
+        if dims == 2 and kernel_size not in (3, (3, 3)):
+            raise NotImplementedError("2-D ResBlock kernel must be 3x3")
+        if dims == 3 and tuple(kernel_size) != (3, 1, 1):
+            raise NotImplementedError("3-D ResBlock kernel must be (3,1,1) (video_kernel_size: [3,1,1])")
+        self.in_layers = nn.Sequential(normalization(channels), SiLU(), conv_nd(dims, channels, self.out_channels, kernel_size, padding=padding))
+        self.updown = False
+        self.emb_layers = nn.Sequential(SiLU(), linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), SiLU(), Dropout(p=dropout),
+                                        zero_module(conv_nd(dims, self.out_channels, self.out_channels, kernel_size, padding=padding)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    def _pack(self, dev):
+        pc = ops.pack_conv3x3 if self.dims == 2 else ops.pack_conv_t3
+        pk = {"conv1": pc(self.in_layers[2].weight, self.in_layers[2].bias, device=dev),
+              "conv2": pc(self.out_layers[3].weight, self.out_layers[3].bias, device=dev),
+              "emb": ops.pack_linear(self.emb_layers[1].weight, self.emb_layers[1].bias, dev)}
+        if not isinstance(self.skip_connection, nn.Identity):
+            pk["skip"] = ops.pack_linear(self.skip_connection.weight, self.skip_connection.bias, dev)
+        return pk
+
+    def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, blend=None):
+        """x (n_img, S, C) bf16; emb_silu (n_img, emb_channels) bf16 = silu(emb).
+        dims=2: returns skip(x) + h.  dims=3 (time_stack): statistics/conv span the T frames of each clip and the result is
+        blend + out_alpha*(conv2 + bias) with blend = x, i.e. AlphaBlender(x_spatial=x, x_temporal=x+h) folded in."""
+        pk = self.packed()
+        n_img, S, _ = x.shape
+        gn1, gn2 = self.in_layers[0], self.out_layers[0]
+        fpg = 1 if self.dims == 2 else T
+        emb_out = ops.linear(emb_silu, pk["emb"], out_f32=True)  # (n_img, Cout): `emb_layers(emb)[..., None, None]`
+        h = ops.groupnorm(x, gn1.weight, gn1.bias, gn1.eps, silu=True, frames_per_group=fpg)
+        if self.dims == 2:
+            h, _, _ = ops.conv3x3(h, pk["conv1"], n_img, H, W, rowvec=emb_out)
+            h = ops.groupnorm(h, gn2.weight, gn2.bias, gn2.eps, silu=True)
+            skip = x if "skip" not in pk else ops.linear(x, pk["skip"])
+            out, _, _ = ops.conv3x3(h, pk["conv2"], n_img, H, W, res1=skip)
+            return out
+        h = ops.conv_t3(h, pk["conv1"], T, S, rowvec=emb_out)
+        h = ops.groupnorm(h, gn2.weight, gn2.bias, gn2.eps, silu=True, frames_per_group=fpg)
+        return ops.conv_t3(h, pk["conv2"], T, S, alpha=out_alpha, res2=x, beta=1.0)
+
+
+class Timestep(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, t):
+        return timestep_embedding(t, self.dim)

@@ -1,0 +1,151 @@
+"""EulerEDM sampler (reference: vwm/modules/diffusionmodules/sampling.py), MI355X-native.
+
+Same constructor and `__call__(denoiser, x, cond, uc, cond_frame, cond_mask, num_steps)` contract as the reference,
+including its in-place scaling of the caller's `x` (sampling.py:36). Two execution paths, identical maths:
+
+  * generic : `denoiser` is any callable `(x, sigma, cond, cond_mask) -> denoised` (e.g. the closure of the reference's
+              sample_utils.py:314-315 around this package's Denoiser/OpenAIWrapper). Per step: mask-replace, guider
+              prepare (cat), denoiser, guider combine, Euler update -- each elementwise stage one HIP kernel.
+  * fused   : `denoiser` is a `FusedDenoiser` (Denoiser + OpenAIWrapper(VideoUNet) of this package). The sigma schedule
+              and the EDM coefficients live on the host as floats (no per-step device sync: the reference syncs twice
+              per step, sampling.py:109 and video_model.py:457), the UNet is entered token-major, and the step's
+              elementwise work is two kernels (vk_sampler_prepare, vk_sampler_update).
+"""
+from typing import Dict, Union
+
+import torch
+
+from ... import ops
+from ...util import append_dims, default, instantiate_from_config
+from .guiders import IdentityGuider
+
+
+class FusedDenoiser:
+    """Callable with the reference closure's signature that also exposes its parts to the sampler's fused path."""
+
+    def __init__(self, denoiser, network):
+        self.denoiser, self.network = denoiser, network
+
+    def __call__(self, x, sigma, cond, cond_mask):
+        return self.denoiser(self.network, x, sigma, cond, cond_mask)
+
+
+class BaseDiffusionSampler:
+    def __init__(self, discretization_config: Union[Dict, None], num_steps: Union[int, None] = None,
+                 guider_config: Union[Dict, None] = None, verbose: bool = False, device: str = "cuda"):
+        self.num_steps = num_steps
+        self.discretization = instantiate_from_config(discretization_config)
+        self.guider = instantiate_from_config(default(guider_config, {"target": "vista_amd.modules.diffusionmodules.guiders.IdentityGuider"}))
+        self.verbose = verbose
+        self.device = device
+
+    def host_sigmas(self, num_steps=None):
+        return self.discretization(self.num_steps if num_steps is None else num_steps, device="cpu").float()
+
+    def prepare_sampling_loop(self, x, cond, uc=None, num_steps=None):
+        sigmas = self.host_sigmas(num_steps)
+        uc = default(uc, cond)
+        s0 = float(torch.sqrt(1.0 + sigmas[0] ** 2))
+        x.copy_(ops.scale_rows(x.float(), torch.full((x.shape[0],), s0, device=x.device)).to(x.dtype))  # in place, like the reference
+        return x, sigmas, len(sigmas), cond, uc
+
+    def denoise(self, x, denoiser, sigma, cond, cond_mask, uc):
+        denoised = denoiser(*self.guider.prepare_inputs(x, sigma, cond, cond_mask, uc))
+        return self.guider(denoised, sigma)
+
+
+class SingleStepDiffusionSampler(BaseDiffusionSampler):
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, uc, *args, **kwargs):
+        raise NotImplementedError
+
+    def euler_step(self, x, d, dt):
+        return x + dt * d
+
+
+class EulerEDMSampler(SingleStepDiffusionSampler):
+    def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+
+    # ---- generic path -------------------------------------------------------------------------------------------
+    def sampler_step(self, sigma, next_sigma, denoiser, x, cond, cond_mask=None, uc=None, gamma=0.0):
+        """sampling.py:78-89. sigma / next_sigma: (N,) device tensors."""
+        sigma_hat = sigma * (gamma + 1.0)
+        if gamma > 0:  # stochastic churn (never enabled by Vista: s_churn = 0, sample_utils.py:212); torch RNG by design
+            eps = torch.randn_like(x) * self.s_noise
+            x = x + eps * append_dims(sigma_hat ** 2 - sigma ** 2, x.ndim) ** 0.5
+        denoised = self.denoise(x, denoiser, sigma_hat, cond, cond_mask, uc)
+        return ops.euler_step(x, denoised.float(), sigma_hat, next_sigma)  # x + (x - denoised)/sigma_hat * (next - sigma_hat)
+
+    @torch.no_grad()
+    def __call__(self, denoiser, x, cond, uc=None, cond_frame=None, cond_mask=None, num_steps=None):
+        x, sigmas, num_sigmas, cond, uc = self.prepare_sampling_loop(x, cond, uc, num_steps)
+        sig = [float(s) for s in sigmas]
+        # the reference evaluates cond_mask.any() on the device; the mask is a host-known 0/1 pattern set by the caller
+        replace = cond_mask is not None and cond_frame is not None and bool(cond_mask.detach().cpu().any())
+        if cond_mask is None:
+            cond_mask = torch.zeros(x.shape[0], device=x.device)
+        maskf = cond_mask.float().contiguous()
+        if isinstance(denoiser, FusedDenoiser) and not isinstance(self.guider, IdentityGuider) and self.s_churn == 0.0 \
+                and x.dim() == 4 and x.shape[1] == 4:
+            return self._sample_fused(denoiser, x, cond, uc, cond_frame, maskf, replace, sig)
+        n = x.shape[0]
+        xw = x.float()
+        for i in range(num_sigmas - 1):
+            if replace:
+                xw = ops.mask_replace(xw, cond_frame.float(), maskf)
+            gamma = min(self.s_churn / (num_sigmas - 1), 2 ** 0.5 - 1) if self.s_tmin <= sig[i] <= self.s_tmax else 0.0
+            s_cur = torch.full((n,), sig[i], device=x.device)
+            s_next = torch.full((n,), sig[i + 1], device=x.device)
+            xw = self.sampler_step(s_cur, s_next, denoiser, xw, cond, maskf, uc, gamma)
+        if replace:
+            xw = ops.mask_replace(xw, cond_frame.float(), maskf)
+        return xw.to(x.dtype)
+
+    # ---- fused path ---------------------------------------------------------------------------------------------
+    def _sample_fused(self, fd, x, cond, uc, cond_frame, maskf, replace, sig):
+        loop = FusedLoop(self, fd, x.float().clone(), cond, uc, cond_frame, maskf, replace, sig)
+        for i in range(len(sig) - 1):
+            loop.step(i)
+        return loop.finish().to(x.dtype)
+
+
+class FusedLoop:
+    """State of one fused sampling run; `step(i)` is exactly one EulerEDMSampler.sampler_step (sampling.py:78-89):
+    mask replace -> CFG-doubled UNet forward -> guider combine -> to_d -> Euler update. bench.py times this."""
+
+    def __init__(self, sampler, fd, xw, cond, uc, cond_frame, maskf, replace, sig):
+        from .video_model import CIN_PAD
+        self.cin_pad = CIN_PAD
+        self.den, self.unet = fd.denoiser, fd.network.diffusion_model
+        self.xw, self.sig, self.replace, self.maskf = xw, sig, replace, maskf
+        n, _, self.H, self.W = xw.shape
+        self.n, self.T = n, self.den.num_frames
+        T, dev = self.T, xw.device
+        self.scales = sampler.guider.frame_scales(T).float().repeat(n // T).to(dev)
+
+        def both(k):
+            a, b = uc[k], cond[k]
+            if a.shape[0] != n:
+                a, b = a.repeat_interleave(T, 0), b.repeat_interleave(T, 0)
+            return a, b
+        cu, cc = both("concat")
+        self.cu, self.cc = cu.float().contiguous(), cc.float().contiguous()
+        self.ctx2 = torch.cat(both("crossattn"), 0)
+        self.y2 = torch.cat(both("vector"), 0)
+        self.mask2 = torch.cat([maskf, maskf])
+        self.cf = cond_frame.float().contiguous() if replace else None
+        # EDM coefficients per step on the host (denoiser_scaling.py:51-59): no device round trip inside the loop
+        self.coef = [tuple(float(v) for v in self.den.scaling(torch.tensor(s, dtype=torch.float32))) for s in sig[:-1]]
+
+    def step(self, i):
+        c_skip, c_out, c_in, c_noise = self.coef[i]
+        net_in = ops.sampler_prepare(self.xw, self.cf, self.maskf, self.cu, self.cc, self.cin_pad, c_in, self.replace)
+        ts = torch.full((2 * self.n,), c_noise, device=self.xw.device)
+        net_out = self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W)
+        ops.sampler_update(self.xw, net_out, self.scales, c_out, c_skip, self.sig[i], self.sig[i + 1])
+
+    def finish(self):
+        if self.replace:
+            self.xw = ops.mask_replace(self.xw, self.cf, self.maskf)
+        return self.xw

@@ -1,0 +1,134 @@
+"""Temporal transformer and the interleaved spatial/temporal block (reference: vwm/modules/video_attention.py).
+
+Token-major layout makes the reference's `(b t) s c <-> (b s) t c` rearranges (video_attention.py:116,140) free:
+LayerNorm, the GEGLU feed-forwards and the q/k/v/out projections are per-token, so they run on the (b t s) row order
+unchanged, and only the 25x25 attention core gathers across frames (vk_attn_temporal_bf16 reads rows with stride S).
+
+  VideoTransformerBlock._forward (video_attention.py:111-141), per pixel over T frames:
+      x = ff_in(norm_in(x)) + x        x_mix = x + frame-pos-emb is fused into the norm_in LayerNorm kernel
+      x = attn1(norm1(x)) + x          fused q|k|v GEMM -> temporal attention -> out GEMM (+res)
+      x = attn2(norm2(x), ctx) + x     one-token context (first frame's, video_attention.py:252-257): per-clip constant
+                                       vector, added as a row vector in the attn1 out-projection epilogue
+      x = ff(norm3(x)) + x             the AlphaBlender mix with the spatial branch is fused into this GEMM's epilogue
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .attention import FeedForward, MemoryEfficientCrossAttention, Packable, SpatialTransformer
+from .diffusionmodules.util import AlphaBlender, LayerNorm, Linear, SiLU, mlp_f32, timestep_embedding
+
+
+class VideoTransformerBlock(nn.Module, Packable):
+    ATTENTION_MODES = {"softmax": MemoryEfficientCrossAttention, "softmax-xformers": MemoryEfficientCrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, use_checkpoint=False, timesteps=None,
+                 ff_in=False, inner_dim=None, attn_mode="softmax", disable_self_attn=False, disable_temporal_crossattention=False,
+                 switch_temporal_ca_to_sa=False, add_lora=False, action_control=False):
+        super().__init__()
+        attn_cls = self.ATTENTION_MODES[attn_mode]
+        self.ff_in = ff_in or inner_dim is not None
+        if inner_dim is None:
+            inner_dim = dim
+        assert int(n_heads * d_head) == inner_dim
+        self.is_res = inner_dim == dim
+        if not self.is_res:
+            raise NotImplementedError("inner_dim != dim is not the Vista configuration")
+        if disable_self_attn or switch_temporal_ca_to_sa:
+            raise NotImplementedError("disable_self_attn / switch_temporal_ca_to_sa are not used by Vista")
+        if self.ff_in:
+            self.norm_in = LayerNorm(dim)
+            self.ff_in = FeedForward(dim, dim_out=inner_dim, dropout=dropout, glu=gated_ff)
+        self.timesteps = timesteps
+        self.disable_self_attn = False
+        self.attn1 = attn_cls(query_dim=inner_dim, heads=n_heads, dim_head=d_head, dropout=dropout, causal=False, add_lora=add_lora)
+        self.attn1.temporal = True
+        self.ff = FeedForward(inner_dim, dim_out=dim, dropout=dropout, glu=gated_ff)
+        self.has_cross = not disable_temporal_crossattention
+        if self.has_cross:
+            self.norm2 = LayerNorm(inner_dim)
+            self.attn2 = attn_cls(query_dim=inner_dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                                  add_lora=add_lora, action_control=action_control)
+        self.norm1 = LayerNorm(inner_dim)
+        self.norm3 = LayerNorm(inner_dim)
+        self.switch_temporal_ca_to_sa = False
+        self.use_checkpoint = use_checkpoint
+        self.n_heads, self.dim = n_heads, dim
+
+    def forward(self, x, emb_rows, clip_context, B, T, S, blend_with, alpha):
+        """x: ((b t) s, dim) bf16 = the spatial branch output; emb_rows: (b*t, dim) f32 frame-position embedding;
+        clip_context: (b, ctx_width) bf16 (context of each clip's first frame). Returns
+        alpha*blend_with + (1-alpha)*temporal_branch  (AlphaBlender, util.py:311-318)."""
+        assert self.timesteps is None or self.timesteps == T
+        if self.ff_in:
+            y, x = ops.layernorm(x, self.norm_in.weight, self.norm_in.bias, self.norm_in.eps, addvec=emb_rows, rows_per_vec=S,
+                                 want_sum=True)  # x <- x + emb (bf16), y = LN(x)
+            x = self.ff_in(y, res1=x)
+        else:
+            raise NotImplementedError("extra_ff_mix_layer=False is not the Vista configuration")
+        a1 = self.attn1.packed()
+        y = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qkv = ops.linear(y, a1["qkv"])
+        att = ops.attn_temporal(qkv, B, T, S, self.n_heads, self.attn1.dim_head ** -0.5)
+        if self.has_cross:
+            cv = self.attn2.context_vector(clip_context)  # (b, dim) f32, constant over the clip's frames and pixels
+            x = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=T * S)
+        else:
+            x = ops.linear(att, a1["out"], res1=x)
+        y = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        return self.ff(y, res1=x, alpha=1.0 - alpha, res2=blend_with, beta=alpha)
+
+
+class SpatialVideoTransformer(SpatialTransformer):
+    """video_attention.py:147-296"""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, use_linear=False, context_dim=None,
+                 use_spatial_context=False, timesteps=None, merge_strategy="fixed", merge_factor=0.5, time_context_dim=None,
+                 ff_in=False, use_checkpoint=False, time_depth=1, attn_mode="softmax", disable_self_attn=False,
+                 disable_temporal_crossattention=False, max_time_embed_period=10000, add_lora=False, action_control=False):
+        super().__init__(in_channels, n_heads, d_head, depth=depth, dropout=dropout, attn_type=attn_mode, use_checkpoint=use_checkpoint,
+                         context_dim=context_dim, use_linear=use_linear, disable_self_attn=disable_self_attn, add_lora=add_lora,
+                         action_control=action_control)
+        self.time_depth = time_depth
+        self.depth = depth
+        self.max_time_embed_period = max_time_embed_period
+        inner_dim = n_heads * d_head
+        if not use_spatial_context:
+            raise NotImplementedError("use_spatial_context=False (separate time_context) is not the Vista configuration")
+        time_context_dim = context_dim
+        self.time_stack = nn.ModuleList([
+            VideoTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=time_context_dim, timesteps=timesteps,
+                                  use_checkpoint=use_checkpoint, ff_in=ff_in, inner_dim=inner_dim, attn_mode=attn_mode,
+                                  disable_self_attn=disable_self_attn, disable_temporal_crossattention=disable_temporal_crossattention,
+                                  add_lora=add_lora, action_control=action_control) for _ in range(self.depth)])
+        assert len(self.time_stack) == len(self.transformer_blocks)
+        self.use_spatial_context = use_spatial_context
+        self.in_channels = in_channels
+        time_embed_dim = in_channels * 4
+        self.time_pos_embed = nn.Sequential(Linear(in_channels, time_embed_dim), SiLU(), Linear(time_embed_dim, in_channels))
+        self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy, rearrange_pattern="b t -> (b t) 1 1")
+        self.n_heads = n_heads
+
+    def _pack(self, dev):
+        return {"proj_in": ops.pack_linear(self.proj_in.weight, self.proj_in.bias, dev),
+                "proj_out": ops.pack_linear(self.proj_out.weight, self.proj_out.bias, dev),
+                "tpe0": ops.pack_linear(self.time_pos_embed[0].weight, self.time_pos_embed[0].bias, dev),
+                "tpe2": ops.pack_linear(self.time_pos_embed[2].weight, self.time_pos_embed[2].bias, dev),
+                "alpha": self.time_mixer.alpha_value()}
+
+    def forward(self, x, context, frame_idx, T, H, W):
+        """x: (n_img, S, C) bf16 tokens; context: (n_img, ctx_width) bf16 (one token per image); frame_idx: (n_img,) f32
+        frame index of every image (arange(T) repeated per clip, video_attention.py:270-271)."""
+        pk = self.packed()
+        n_img, S, C = x.shape
+        B = n_img // T
+        x_in = x
+        h = ops.groupnorm(x, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
+        h = ops.linear(h, pk["proj_in"])                                           # (n_img*S, C)
+        emb = mlp_f32(timestep_embedding(frame_idx, self.in_channels, self.max_time_embed_period), pk["tpe0"], pk["tpe2"])
+        clip_context = context.view(B, T, -1)[:, 0]                                # context[::T] (first frame of each clip)
+        for block, mix_block in zip(self.transformer_blocks, self.time_stack):
+            h = block(h, context, n_img, S)
+            h = mix_block(h, emb, clip_context, B, T, S, blend_with=h, alpha=pk["alpha"])
+        out = ops.linear(h, pk["proj_out"], res1=x_in)
+        return out.view(n_img, S, C)

@@ -222,13 +222,23 @@ def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1
 
 
 # ---------------------------------------------------------------------------------------------- attention
+PROFILE_ATTN = None  # bench.py sets this to a list: (S, n_img*heads, start_event, end_event) per launch, on the launch stream
+
+
 def attn_spatial(q, k, vt, n_img, heads, S, scale=None):
     """q, k: 2-D strided views (n_img*S, heads*64) bf16; vt (n_img, heads*64, S). Returns (n_img*S, heads*64)."""
     _need(q, BF16, "q"); _need(k, BF16, "k"); _need(vt, BF16, "vt")
     o = torch.empty((n_img * S, heads * 64), dtype=BF16, device=q.device)
     lib = _lib.load()
+    ev = None
+    if PROFILE_ATTN is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     check(lib.vk_attn_spatial_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), o.stride(0),
                                    float(scale if scale is not None else 1.0 / math.sqrt(64)), _stream()), "vk_attn_spatial_bf16")
+    if ev is not None:
+        ev[1].record()
+        PROFILE_ATTN.append((S, n_img * heads, ev[0], ev[1]))
     return o
 
 
@@ -352,7 +362,12 @@ def sampler_update(x, net_out, scale, c_out, c_skip, sigma, sigma_next):
     return x
 
 
+def _c(*ts):
+    return [t.contiguous() for t in ts]
+
+
 def denoiser_combine(net, x, c_out, c_skip):
+    net, x, c_out, c_skip = _c(net, x, c_out, c_skip)
     out = torch.empty_like(x)
     n = x.shape[0]
     check(_lib.load().vk_denoiser_combine(_p(net), _p(x), _p(c_out), _p(c_skip), _p(out), n, x.numel() // n, _stream()),
@@ -361,6 +376,7 @@ def denoiser_combine(net, x, c_out, c_skip):
 
 
 def cfg_combine(x2, scale):
+    x2, scale = _c(x2, scale)
     T = x2.shape[0] // 2
     out = torch.empty((T,) + tuple(x2.shape[1:]), dtype=F32, device=x2.device)
     check(_lib.load().vk_cfg_combine(_p(x2), _p(scale), _p(out), T, out.numel() // T, _stream()), "vk_cfg_combine")
@@ -368,6 +384,7 @@ def cfg_combine(x2, scale):
 
 
 def euler_step(x, den, sigma, sigma_next):
+    x, den, sigma, sigma_next = _c(x, den, sigma, sigma_next)
     out = torch.empty_like(x)
     n = x.shape[0]
     check(_lib.load().vk_euler_step(_p(x), _p(den), _p(sigma), _p(sigma_next), _p(out), n, x.numel() // n, _stream()), "vk_euler_step")
@@ -375,6 +392,7 @@ def euler_step(x, den, sigma, sigma_next):
 
 
 def mask_replace(x, cond, mask):
+    x, cond, mask = _c(x, cond, mask)
     out = torch.empty_like(x)
     n = x.shape[0]
     check(_lib.load().vk_mask_replace(_p(x), _p(cond), _p(mask), _p(out), n, x.numel() // n, _stream()), "vk_mask_replace")
@@ -382,6 +400,7 @@ def mask_replace(x, cond, mask):
 
 
 def scale_rows(x, s):
+    x, s = _c(x, s)
     out = torch.empty_like(x)
     n = x.shape[0]
     check(_lib.load().vk_scale_rows(_p(x), _p(s), _p(out), n, x.numel() // n, _stream()), "vk_scale_rows")
