@@ -29,6 +29,7 @@ def build_model(model_channels, seed=0):
     from vista_amd.modules.diffusionmodules.video_model import VideoUNet
     with torch.device("cuda"):
         net = VideoUNet(**unet_kwargs(model_channels))
+    net = net.cuda()
     g = torch.Generator(device="cuda").manual_seed(seed)
     with torch.no_grad():  # re-randomise EVERY tensor: the default init zeroes 403 of them and the net would output 0
         for name, p in net.named_parameters():

@@ -66,7 +66,8 @@ int vk_attn_temporal_bf16(const void* qkv, void* o, int32_t B, int32_t T, int32_
  * temporal ResBlock whose statistics cover (C/32, T, H, W)).
  * Replaces GroupNorm32/Normalize + nn.SiLU: vwm/modules/diffusionmodules/util.py:196-216, attention.py:141-142,
  * openaimodel.py:195-199,227-230, video_model.py:434-436.
- * stats_ws: f32 workspace of 2*32*(n_img/frames_per_group) floats (zeroed by the call). */
+ * stats_ws: f32 workspace of 64*(n_img/frames_per_group) + 64*n_img*ceil(S/128) floats (fixed-order partial sums:
+ * results are bitwise reproducible, no atomics). */
 int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
                            int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group, float eps, int32_t silu,
                            void* stream);

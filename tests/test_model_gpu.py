@@ -120,8 +120,9 @@ def test_sampler_and_denoiser_vs_reference_golden():
 
 
 def test_unet_properties_batch_and_determinism():
-    """Size-independent properties: clips in a batch are independent (running [A;B] == running A and B) and repeated
-    runs agree up to the fp32 atomics order of the GroupNorm statistics."""
+    """Size-independent properties: clips in a batch are independent (running [A;B] == running A and B) and repeated runs
+    are bitwise identical (every reduction, including the GroupNorm statistics, runs in a fixed order: no atomics).
+    bf16 rounding amplifies ANY low-order difference to the 1e-2 noise floor over ~100 layers, so these are strict."""
     from oracle.make_golden import unet_inputs
     net, _ = tiny_unet()
     T, H, W = 5, 16, 32
@@ -131,9 +132,9 @@ def test_unet_properties_batch_and_determinism():
     oa = net(xa[0], timesteps=xa[1], context=xa[2], y=xa[3], cond_mask=xa[4], num_frames=T)
     ob = net(xb[0], timesteps=xb[1], context=xb[2], y=xb[3], cond_mask=xb[4], num_frames=T)
     oab = net(xs[0], timesteps=xs[1], context=xs[2], y=xs[3], cond_mask=xs[4], num_frames=T)
-    assert rel_l2(oab[:2 * T], oa) < 2e-3 and rel_l2(oab[2 * T:], ob) < 2e-3
+    assert torch.equal(oab[:2 * T], oa) and torch.equal(oab[2 * T:], ob)
     oa2 = net(xa[0], timesteps=xa[1], context=xa[2], y=xa[3], cond_mask=xa[4], num_frames=T)
-    assert rel_l2(oa2, oa) < 1e-3
+    assert torch.equal(oa2, oa)
 
 
 def test_product_path_refuses_cpu():

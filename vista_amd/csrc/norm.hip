@@ -6,7 +6,8 @@
 // image-group is `frames_per_group` consecutive images -- 1 for the 2-D norms, T for the temporal ResBlock's 5-D norm
 // whose statistics span (C/32, T, H, W) (openaimodel.py:196,228 on `b c t h w`). Two launches:
 //   stats : every thread owns one fixed 16-B channel chunk and strides over tokens, keeping 8 per-channel fp32
-//           partial (sum, sumsq) pairs -> folded per group into LDS atomics -> one global atomic per group.
+//           partial (sum, sumsq) pairs; partials are combined in a fixed order (no atomics) through LDS and a
+//           per-chunk workspace, then a finalize launch produces mean / rstd -> bitwise reproducible results.
 //   apply : same ownership; per-channel scale/shift folded once into 16 registers, then a pure streaming pass
 //           y = silu(x*a + b).
 #include "common.h"
@@ -16,17 +17,18 @@ namespace {
 
 constexpr int GN_TOK = 128;  // tokens per workgroup
 
-__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ stats, int S, int C, int CG, int R,
-                                int frames_per_group) {
-    __shared__ float lsum[32], lsq[32];
+// stats pass 1: per (image, 128-token chunk) partial (sum, sumsq) of the 32 groups, reduced in a FIXED order
+// (thread partials -> LDS [r][channel] -> per-channel over r -> per-group over channels): bitwise reproducible.
+__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial, int S, int C, int CG, int R) {
+    extern __shared__ float lds[];  // [2][R][C]
     const int tid = threadIdx.x;
-    if (tid < 32) { lsum[tid] = 0.f; lsq[tid] = 0.f; }
-    __syncthreads();
     const int img = blockIdx.y;
     const int tok0 = blockIdx.x * GN_TOK;
     const int tok1 = min(tok0 + GN_TOK, S);
     const int chunk = tid % CG, r = tid / CG;
     const int cpg = C >> 5;
+    float* lsum = lds;
+    float* lsq = lds + R * C;
     if (r < R) {
         float sm[8], sq[8];
 #pragma unroll
@@ -39,27 +41,47 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] = fmaf(f[e], f[e], sq[e]); }
         }
-        // fold the 8 per-channel partials into their groups (a chunk may straddle several groups for any cpg)
-        int gprev = (chunk * 8) / cpg;
-        float as = 0.f, aq = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (chunk * 8 + e) / cpg;
-            if (g != gprev) {
-                atomicAdd(&lsum[gprev], as);
-                atomicAdd(&lsq[gprev], aq);
-                as = 0.f; aq = 0.f; gprev = g;
-            }
-            as += sm[e]; aq += sq[e];
+            lsum[r * C + chunk * 8 + e] = sm[e];
+            lsq[r * C + chunk * 8 + e] = sq[e];
         }
-        atomicAdd(&lsum[gprev], as);
-        atomicAdd(&lsq[gprev], aq);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {  // per-channel totals over the R token lanes, fixed order
+        float a = 0.f, b = 0.f;
+        for (int rr = 0; rr < R; ++rr) { a += lsum[rr * C + c]; b += lsq[rr * C + c]; }
+        lsum[c] = a;
+        lsq[c] = b;
     }
     __syncthreads();
     if (tid < 32) {
-        float* st = stats + (size_t)(img / frames_per_group) * 64;
-        atomicAdd(st + tid, lsum[tid]);
-        atomicAdd(st + 32 + tid, lsq[tid]);
+        float a = 0.f, b = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += lsum[c]; b += lsq[c]; }
+        float* dst = partial + ((size_t)img * gridDim.x + blockIdx.x) * 64;
+        dst[tid] = a;
+        dst[32 + tid] = b;
+    }
+}
+
+// stats pass 2: one workgroup per image-group; sums the (frames_per_group x chunks) partials of each of the 64 values
+// in a fixed order (4 strided lanes per value, then a fixed 4-way combine) and writes mean / rstd.
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nparts, float inv_cnt, float eps) {
+    __shared__ float red[4][64];
+    const int v = threadIdx.x & 63, j = threadIdx.x >> 6;  // 256 threads
+    const float* src = partial + (size_t)blockIdx.x * nparts * 64 + v;
+    float a = 0.f;
+    for (int i = j; i < nparts; i += 4) a += src[(size_t)i * 64];
+    red[j][v] = a;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int g = threadIdx.x;
+        const float sum = (red[0][g] + red[1][g]) + (red[2][g] + red[3][g]);
+        const float sq = (red[0][32 + g] + red[1][32 + g]) + (red[2][32 + g] + red[3][32 + g]);
+        const float mean = sum * inv_cnt;
+        const float var = fmaxf(sq * inv_cnt - mean * mean, 0.f);
+        stats[(size_t)blockIdx.x * 64 + g] = mean;
+        stats[(size_t)blockIdx.x * 64 + 32 + g] = rsqrtf(var + eps);
     }
 }
 
@@ -73,18 +95,14 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
     const int chunk = tid % CG, r = tid / CG;
     if (r >= R) return;
     const int cpg = C >> 5;
-    const float inv_cnt = 1.f / ((float)cpg * (float)S * (float)frames_per_group);
-    const float* st = stats + (size_t)(img / frames_per_group) * 64;
+    const float* st = stats + (size_t)(img / frames_per_group) * 64;  // [32 means | 32 rstds]
     float a[8], b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = chunk * 8 + e;
         const int g = c / cpg;
-        const float mean = st[g] * inv_cnt;
-        const float var = fmaxf(st[32 + g] * inv_cnt - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + eps);
-        a[e] = gamma[c] * rstd;
-        b[e] = beta[c] - mean * a[e];
+        a[e] = gamma[c] * st[32 + g];
+        b[e] = beta[c] - st[g] * a[e];
     }
     const size_t base = ((size_t)img * S) * C + chunk * 8;
     for (int t = tok0 + r; t < tok1; t += R) {
@@ -183,10 +201,17 @@ extern "C" int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma
     int R = 256 / CG;
     if (R < 1) R = 1;
     const int threads = ((CG * R + 63) / 64) * 64;
-    const size_t nstat = (size_t)(n_img / frames_per_group) * 64;
-    if (hipMemsetAsync(stats_ws, 0, nstat * sizeof(float), stream) != hipSuccess) return VK_ELAUNCH;
-    dim3 grid((S + GN_TOK - 1) / GN_TOK, n_img);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), 0, stream, (const uint16_t*)x, stats_ws, S, C, CG, R, frames_per_group);
+    // workspace: [n_img/fpg][64] mean|rstd, then [n_img][chunks][64] partial sums
+    const int nchunks = (S + GN_TOK - 1) / GN_TOK;
+    const int ngroups = n_img / frames_per_group;
+    float* partial = stats_ws + (size_t)ngroups * 64;
+    dim3 grid(nchunks, n_img);
+    const size_t lds_bytes = (size_t)2 * R * C * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), lds_bytes, stream, (const uint16_t*)x, partial, S, C, CG, R);
+    VK_CHECK_LAUNCH();
+    const float inv_cnt = 1.f / ((float)(C / 32) * (float)S * (float)frames_per_group);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ngroups), dim3(256), 0, stream, (const float*)partial, stats_ws,
+                       frames_per_group * nchunks, inv_cnt, eps);
     VK_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, (const uint16_t*)x, (uint16_t*)y, gamma, beta,
                        (const float*)stats_ws, S, C, CG, R, frames_per_group, eps, silu);

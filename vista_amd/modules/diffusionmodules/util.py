@@ -117,9 +117,9 @@ class AlphaBlender(nn.Module):
         self.merge_strategy = merge_strategy
         self.rearrange_pattern = rearrange_pattern
         if merge_strategy == "fixed":
-            self.register_buffer("mix_factor", torch.Tensor([alpha]))
+            self.register_buffer("mix_factor", torch.tensor([float(alpha)], dtype=torch.float32))
         else:
-            self.register_parameter("mix_factor", nn.Parameter(torch.Tensor([alpha])))
+            self.register_parameter("mix_factor", nn.Parameter(torch.tensor([float(alpha)], dtype=torch.float32)))
 
     def alpha_value(self):
         """Host float (one D2H read at pack time, never per step)."""
