@@ -337,3 +337,45 @@ def test_sampler_elementwise():
     co = torch.randn(T, device="cuda"); cs = torch.randn(T, device="cuda")
     assert torch.allclose(ops.denoiser_combine(xb, cf, co, cs), xb * co.view(-1, 1, 1, 1) + cf * cs.view(-1, 1, 1, 1), atol=1e-5)
     assert torch.allclose(ops.scale_rows(xb, co), xb * co.view(-1, 1, 1, 1), atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ block-tile variants
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_family_all_tile_configs(cfg):
+    """Every block-tile variant (128x128, 256x128, 256x256) of every loader / epilogue, on shapes with ragged M and N edges."""
+    ops = _ops()
+    ops.TILE_CFG = cfg
+    try:
+        M, N, K = 1100, 960, 640
+        x = rnd(M, K)
+        w = rnd(N, K, scale=K ** -0.5, seed=1)
+        b = rnd(N, seed=2).float()
+        r1 = rnd(M, N, seed=4)
+        out = ops.linear(x, ops.pack_linear(w, b), res1=r1, alpha=0.5)
+        close(out, 0.5 * (x.float() @ w.float().t() + b + r1.float()), f"linear cfg{cfg}")
+        C = 320
+        xg = rnd(700, C)
+        wg = rnd(8 * C, C, scale=C ** -0.5, seed=1)
+        bg = rnd(8 * C, seed=2).float()
+        h = xg.float() @ wg.float().t() + bg
+        a, g = h.chunk(2, dim=-1)
+        close(ops.linear(xg, ops.pack_geglu(wg, bg)), a * F.gelu(g), f"geglu cfg{cfg}")
+        n_img, S = 3, 400
+        xv = rnd(n_img * S, C)
+        wv = rnd(C, C, scale=C ** -0.5, seed=3)
+        close(ops.linear_vt(xv, ops.pack_linear(wv, None), S), (xv.float() @ wv.float().t()).view(n_img, S, C).transpose(1, 2), f"vt cfg{cfg}")
+        n, H, W, Cin, Cout = 3, 18, 32, 128, 320
+        xc = rnd(n, H * W, Cin)
+        wc = rnd(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5, seed=1)
+        bc = rnd(Cout, seed=2).float()
+        oc, _, _ = ops.conv3x3(xc, ops.pack_conv3x3(wc, bc), n, H, W)
+        close(oc, _nchw2tok(F.conv2d(_tok2nchw(xc, n, H, W), wc.float(), bc, padding=1)), f"conv cfg{cfg}")
+        B, T, S2, Ct = 2, 5, 130, 128
+        xt = rnd(B * T, S2, Ct)
+        wt = rnd(Ct, Ct, 3, 1, 1, scale=(3 * Ct) ** -0.5, seed=1)
+        bt = rnd(Ct, seed=2).float()
+        ot = ops.conv_t3(xt, ops.pack_conv_t3(wt, bt), T, S2)
+        x5 = xt.float().view(B, T, S2, 1, Ct).permute(0, 4, 1, 2, 3)
+        close(ot, F.conv3d(x5, wt.float(), bt, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(B * T, S2, Ct), f"conv_t3 cfg{cfg}")
+    finally:
+        ops.TILE_CFG = 0

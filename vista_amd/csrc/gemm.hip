@@ -7,8 +7,11 @@
 //   TEMPORAL3  3x1x1 conv over frames, pad (1,0,0)   (video_model.py:38-52 time_stack)
 // W is [Npad][K] with K contiguous (= nn.Linear.weight layout; conv weights are packed [Cout][tap][Cin]).
 //
-// Tiling: 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32x16 bf16 tiles, fp32 accumulate.
-// LDS: two stages of (A 16 KiB + W 16 KiB); rows are 128 B (64 bf16) and the 16-B chunk index is XOR-swizzled
+// Tiling (template): block tile BM x BN x 64 with WM x WN waves, each wave FM x FN MFMA 32x32x16 bf16 tiles, fp32 accumulate.
+//   256x256 (8 waves 2x4, wave tile 128x64)  large-N GEMMs/convs: halves LDS-fill and cuts fragment-read bytes per FLOP
+//   256x128 (8 waves 4x2, wave tile  64x64)  N <= 384 (the 320-channel level)
+//   128x128 (4 waves 2x2, wave tile  64x64)  small problems (embedding MLPs, context vectors)
+// LDS: two stages of (A tile + W tile); rows are 128 B (64 bf16) and the 16-B chunk index is XOR-swizzled
 // with (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free. Global->LDS goes through registers
 // (prefetch tile t+1 while computing tile t; one barrier per K-step).
 // The MFMA is issued "swapped" (weights are the row/A operand, activations the column/B operand) so that a lane
@@ -22,19 +25,26 @@ namespace {
 enum { AMODE_DENSE = 0, AMODE_CONV3X3 = 1, AMODE_TEMPORAL3 = 2 };
 enum { EPI_LINEAR = 0, EPI_GEGLU = 1, EPI_TRANS = 2 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = 32768;  // A tile 16 KiB + W tile 16 KiB
+constexpr int BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int AMODE, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
+template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc p) {
+    constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
+    constexpr int NT = WM * WN * 64;              // threads
+    constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 x 16-B chunks per 128-B row)
+    constexpr int AP = BM / RPP, WP = BN / RPP;   // staging passes for the A / W tiles
+    constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+    constexpr bool TR = (EPI == EPI_TRANS);
+    constexpr int FX = TR ? FM : FN, FY = TR ? FN : FM;  // MFMA row-operand / column-operand fragments per wave
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, lh = lane >> 5;
 
     const int tilesN = (p.N + BN - 1) / BN;
@@ -49,19 +59,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
     // ---- per-thread global->LDS staging assignment: chunk lc of rows lr + 32*i ----
     const int lc = tid & 7;
     const int lr = tid >> 3;
-    const int st_off = lds_off(lr, lc);  // (row>>1)&7 is invariant under +32*i
+    const int st_off = lds_off(lr, lc);  // (row>>1)&7 is invariant under +RPP*i (RPP is a multiple of 16)
 
-    const uint16_t* wptr[4];
+    const uint16_t* wptr[WP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wptr[i] = Wg + (size_t)(n0 + lr + 32 * i) * p.K + lc * 8;
+    for (int i = 0; i < WP; ++i) wptr[i] = Wg + (size_t)(n0 + lr + RPP * i) * p.K + lc * 8;
 
     // A-row state
-    const uint16_t* aptr[4];
-    int a_y0[4], a_x0[4];
-    bool a_ok[4];
+    const uint16_t* aptr[AP];
+    int a_y0[AP], a_x0[AP];
+    bool a_ok[AP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + lr + 32 * i;
+    for (int i = 0; i < AP; ++i) {
+        int m = m0 + lr + RPP * i;
         a_ok[i] = m < p.M;
         if (m >= p.M) m = p.M - 1;
         if (AMODE == AMODE_DENSE) {
@@ -83,22 +93,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
         }
     }
 
-    uint4 ra[4], rw[4];
+    uint4 ra[AP], rw[WP];
     int tap = 0, c0 = 0;  // (tap, channel offset) of the current K-step for the conv loaders
 
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rw[i] = *(const uint4*)(wptr[i] + k0);
+        for (int i = 0; i < WP; ++i) rw[i] = *(const uint4*)(wptr[i] + k0);
         if (AMODE == AMODE_DENSE) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = *(const uint4*)(aptr[i] + k0);
+            for (int i = 0; i < AP; ++i) ra[i] = *(const uint4*)(aptr[i] + k0);
         } else if (AMODE == AMODE_CONV3X3) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int sh = p.ups - 1;
             const int He = p.H << sh, We = p.Wd << sh;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < AP; ++i) {
                 const int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
                 const bool ok = a_ok[i] && iy >= 0 && iy < He && ix >= 0 && ix < We;
                 const int sy = iy >> sh, sx = ix >> sh;
@@ -108,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
         } else {
             const int dt = tap - 1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < AP; ++i) {
                 const int t = a_y0[i] + dt;
                 const bool ok = a_ok[i] && t >= 0 && t < p.T;
                 if (ok) ra[i] = *(const uint4*)(aptr[i] + ((ptrdiff_t)dt * p.S * p.Cin + c0));
@@ -120,27 +130,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
     };
     auto store_tile = [&](int stage) {
         char* sA = smem + stage * STAGE_BYTES;
-        char* sW = sA + 16384;
+        char* sW = sA + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(uint4*)(sA + st_off + i * 32 * 128) = ra[i];
-            *(uint4*)(sW + st_off + i * 32 * 128) = rw[i];
-        }
+        for (int i = 0; i < AP; ++i) *(uint4*)(sA + st_off + i * RPP * 128) = ra[i];
+#pragma unroll
+        for (int i = 0; i < WP; ++i) *(uint4*)(sW + st_off + i * RPP * 128) = rw[i];
     };
 
-    f32x16_t acc[2][2];
+    f32x16_t acc[FX][FY];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < FX; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < FY; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // X = MFMA row operand, Y = MFMA column operand. Normal: X = weights, Y = activations. TRANS: swapped.
-    const int xoff = (EPI == EPI_TRANS) ? wm * 64 : wn * 64;
-    const int yoff = (EPI == EPI_TRANS) ? wn * 64 : wm * 64;
-    const int xbase = (EPI == EPI_TRANS) ? 0 : 16384;   // X tile lives in sA (TRANS) or sW
-    const int ybase = (EPI == EPI_TRANS) ? 16384 : 0;
+    constexpr int MW = FM * 32, NW = FN * 32;  // wave tile extents along m / n
+    const int xoff = TR ? wm * MW : wn * NW;
+    const int yoff = TR ? wn * NW : wm * MW;
+    const int xbase = TR ? 0 : A_BYTES;   // X tile lives in sA (TRANS) or sW
+    const int ybase = TR ? A_BYTES : 0;
     const int sw = (l31 >> 1) & 7;
     int frag_off[4];  // byte offset of k-substep ks inside a row
 #pragma unroll
@@ -158,16 +168,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
         const char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t xf[2], yf[2];
+            bf16x8_t xf[FX], yf[FY];
 #pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                xf[f] = *(const bf16x8_t*)(sb + xbase + xrow_off + f * 32 * 128 + frag_off[ks]);
-                yf[f] = *(const bf16x8_t*)(sb + ybase + yrow_off + f * 32 * 128 + frag_off[ks]);
-            }
+            for (int f = 0; f < FX; ++f) xf[f] = *(const bf16x8_t*)(sb + xbase + xrow_off + f * 32 * 128 + frag_off[ks]);
 #pragma unroll
-            for (int fi = 0; fi < 2; ++fi)
+            for (int f = 0; f < FY; ++f) yf[f] = *(const bf16x8_t*)(sb + ybase + yrow_off + f * 32 * 128 + frag_off[ks]);
 #pragma unroll
-                for (int fj = 0; fj < 2; ++fj)
+            for (int fi = 0; fi < FX; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < FY; ++fj)
                     acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
         }
         if (kt + 1 < nk) store_tile(stage ^ 1);
@@ -182,15 +191,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
         const uint16_t* __restrict__ res1 = (const uint16_t*)p.res1;
         const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
 #pragma unroll
-        for (int fj = 0; fj < 2; ++fj) {
-            const int m = m0 + wm * 64 + fj * 32 + l31;
+        for (int fj = 0; fj < FY; ++fj) {
+            const int m = m0 + wm * MW + fj * 32 + l31;
             if (m >= p.M) continue;
             const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
 #pragma unroll
-            for (int fi = 0; fi < 2; ++fi) {
+            for (int fi = 0; fi < FX; ++fi) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * 64 + fi * 32 + 8 * g + 4 * lh;
+                    const int n = n0 + wn * NW + fi * 32 + 8 * g + 4 * lh;
                     if (n >= p.N) continue;
                     float v[4];
 #pragma unroll
@@ -226,12 +235,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
             }
         }
     } else if (EPI == EPI_GEGLU) {
-        // packed weight rows: tile of 128 = 2 x [32 value rows | 32 gate rows]; fi=0 value, fi=1 gate
+        // packed weight rows: every 64-row wave slice = [32 value rows | 32 gate rows]; fi=0 value, fi=1 gate
+        static_assert(EPI != EPI_GEGLU || FN == 2, "GEGLU packing assumes a 64-column wave tile");
         const float* __restrict__ bias = p.bias;
         const int nout = p.N >> 1;
 #pragma unroll
-        for (int fj = 0; fj < 2; ++fj) {
-            const int m = m0 + wm * 64 + fj * 32 + l31;
+        for (int fj = 0; fj < FY; ++fj) {
+            const int m = m0 + wm * MW + fj * 32 + l31;
             if (m >= p.M) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -255,14 +265,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
         }
     } else {  // EPI_TRANS: out[img][n][key], key = m % S contiguous
 #pragma unroll
-        for (int fj = 0; fj < 2; ++fj) {
-            const int n = n0 + wn * 64 + fj * 32 + l31;
+        for (int fj = 0; fj < FY; ++fj) {
+            const int n = n0 + wn * NW + fj * 32 + l31;
             if (n >= p.N) continue;
 #pragma unroll
-            for (int fi = 0; fi < 2; ++fi) {
+            for (int fi = 0; fi < FX; ++fi) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int m = m0 + wm * 64 + fi * 32 + 8 * g + 4 * lh;
+                    const int m = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh;
                     if (m >= p.M) continue;
                     const int img = m / p.S;
                     const int key = m - img * p.S;
@@ -276,13 +286,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const VkGemmDesc p) {
     }
 }
 
-template <int AMODE, int EPI, bool OUT_F32>
-int launch(const VkGemmDesc* d, hipStream_t stream) {
+template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
+int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
+    constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tilesN = (d->N + BN - 1) / BN;
     const int tilesM = (d->M + BM - 1) / BM;
-    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32>), dim3(tilesM * tilesN), dim3(256), 0, stream, *d);
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, *d);
     VK_CHECK_LAUNCH();
     return VK_OK;
+}
+
+// Tile-shape choice (host side, per problem): small problems keep the 128x128 tile; otherwise 256x256 unless rounding N up
+// to 256 wastes more than ~10% of the MFMA work, in which case 256x128.
+template <int AMODE, int EPI, bool OUT_F32>
+int launch(const VkGemmDesc* d, hipStream_t stream) {
+    const int force = d->tile_cfg;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (tests / tuning)
+    int cfg = force;
+    if (cfg == 0) {
+        if ((long long)d->M * d->N < (1LL << 21) || d->M < 1024) cfg = 1;
+        else {
+            const int n256 = (d->N + 255) / 256 * 256;
+            cfg = (n256 * 10 <= d->N * 11) ? 3 : 2;
+        }
+    }
+    if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 2, 4, 4, 2>(d, stream);
+    if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 2>(d, stream);
+    return launch_cfg<AMODE, EPI, OUT_F32, 2, 2, 2, 2>(d, stream);
 }
 
 }  // namespace
@@ -290,7 +319,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || d->tile_cfg > 3) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;

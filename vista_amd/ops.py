@@ -48,7 +48,7 @@ def ceil_to(x, m):
 
 # ---------------------------------------------------------------------------------------------- weight packing
 class PackedWeight:
-    """bf16 [ceil128(N)][K] weight (K contiguous) + f32 bias, laid out for vk_gemm_bf16."""
+    """bf16 [ceil256(N)][K] weight (K contiguous) + f32 bias, laid out for vk_gemm_bf16."""
 
     __slots__ = ("wt", "bias", "N", "K", "geglu")
 
@@ -59,7 +59,7 @@ class PackedWeight:
 def _finish_pack(w2d, bias, device, geglu=False):
     N, K = w2d.shape
     Kp = ceil_to(K, 64)
-    Np = ceil_to(N, 128)
+    Np = ceil_to(N, 256)
     wt = torch.zeros((Np, Kp), dtype=BF16, device=device)
     wt[:N, :K] = w2d.to(device=device, dtype=BF16)
     b = None
@@ -113,8 +113,12 @@ def pack_conv_t3(weight, bias=None, device="cuda"):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM family
+TILE_CFG = 0  # 0 = auto; tests force 1/2/3 to cover every block-tile variant
+
+
 def _gemm(desc):
     lib = _lib.load()
+    desc.tile_cfg = TILE_CFG
     check(lib.vk_gemm_bf16(C.byref(desc), _stream()), "vk_gemm_bf16")
 
 
