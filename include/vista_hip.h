@@ -22,7 +22,7 @@ enum { VK_EPI_LINEAR = 0, VK_EPI_GEGLU = 1, VK_EPI_TRANS = 2 };
 
 typedef struct VkGemmDesc {
     const void* A;       /* bf16 activations: [M][lda] (DENSE) or NHWC source image stack (conv modes)            */
-    const void* Wt;      /* bf16 weights [ceil256(N)][K], K contiguous; conv: [Cout][tap][Cin]                    */
+    const void* Wt;      /* bf16 weights [pad(N)][K] (pad: multiple of 256 and >= ceil320(N)), K contiguous; conv: [Cout][tap][Cin]                    */
     void* out;           /* bf16 or f32 [M][ldc]; EPI_TRANS: bf16 [M/S][N][S]                                     */
     const float* bias;   /* [ceil256(N)] f32 or NULL (EPI_GEGLU: in packed row order)                             */
     const float* rowvec; /* f32 [M/rows_per_vec][ldv] added per image, or NULL                                    */
@@ -34,8 +34,9 @@ typedef struct VkGemmDesc {
     int32_t amode, epi, out_f32;
     int32_t H, Wd, Cin, Hout, Wout, stride, ups; /* CONV3X3: source H x Wd (before the x`ups` nearest upsample)   */
     int32_t T, S;        /* TEMPORAL3: frames per clip, tokens per frame. EPI_TRANS: S = tokens per image         */
-    int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile (tests / tuning). Weights must be
-                            padded to a multiple of 256 rows.                                                      */
+    int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning).
+                            Weight rows
+                            are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                                                      */
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:

@@ -9,7 +9,9 @@
 //
 // Tiling (template): block tile BM x BN x 64 with WM x WN waves, each wave FM x FN MFMA 32x32x16 bf16 tiles, fp32 accumulate.
 //   256x256 (8 waves 2x4, wave tile 128x64)  large-N GEMMs/convs: halves LDS-fill and cuts fragment-read bytes per FLOP
-//   256x128 (8 waves 4x2, wave tile  64x64)  N <= 384 (the 320-channel level)
+//   256x320 (8 waves 4x2, wave tile  64x160) N a multiple of 320 (every channel count of the shipped UNet): no padded
+//                                            columns, and the conv gather of A runs once per 320 output channels
+//   256x128 (8 waves 4x2, wave tile  64x64)  other narrow N
 //   128x128 (4 waves 2x2, wave tile  64x64)  small problems (embedding MLPs, context vectors)
 // LDS: two stages of (A tile + W tile); rows are 128 B (64 bf16) and the 16-B chunk index is XOR-swizzled
 // with (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free. Global->LDS goes through registers
@@ -157,14 +159,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
     for (int ks = 0; ks < 4; ++ks) frag_off[ks] = ((ks * 2 + lh) ^ sw) << 4;
     const int xrow_off = (xoff + l31) * 128, yrow_off = (yoff + l31) * 128;
 
+    // Software pipeline: registers run TWO tiles ahead of the MFMAs, LDS one. In iteration kt the registers (tile kt+1,
+    // fetched during iteration kt-1) are written into the LDS stage that became free at the previous barrier while the
+    // MFMAs consume the other stage, and the global loads of tile kt+2 are issued right after -- so HBM/L2 latency is
+    // covered by a whole K-step and the LDS fill overlaps the matrix pipe instead of following it.
     const int nk = p.K / BK;
     load_tile(0);
     store_tile(0);
+    if (nk > 1) load_tile(1);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) store_tile(stage ^ 1);
+        if (kt + 2 < nk) load_tile(kt + 2);
         const char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -179,7 +187,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
                 for (int fj = 0; fj < FY; ++fj)
                     acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(stage ^ 1);
         __syncthreads();
     }
 
@@ -300,14 +307,19 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
 // to 256 wastes more than ~10% of the MFMA work, in which case 256x128.
 template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
-    const int force = d->tile_cfg;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256 (tests / tuning)
+    const int force = d->tile_cfg;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (tests / tuning)
     int cfg = force;
+    if (cfg == 4 && EPI == EPI_GEGLU) cfg = 3;  // the GEGLU packing needs 64-column wave tiles
     if (cfg == 0) {
         if ((long long)d->M * d->N < (1LL << 21) || d->M < 1024) cfg = 1;
+        else if (EPI != EPI_GEGLU && d->N % 320 == 0) cfg = 4;
         else {
             const int n256 = (d->N + 255) / 256 * 256;
             cfg = (n256 * 10 <= d->N * 11) ? 3 : 2;
         }
+    }
+    if constexpr (EPI != EPI_GEGLU) {
+        if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 5>(d, stream);
     }
     if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 2, 4, 4, 2>(d, stream);
     if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 2>(d, stream);
@@ -319,7 +331,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || d->tile_cfg > 3) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || d->tile_cfg > 4) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;

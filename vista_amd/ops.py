@@ -59,7 +59,7 @@ class PackedWeight:
 def _finish_pack(w2d, bias, device, geglu=False):
     N, K = w2d.shape
     Kp = ceil_to(K, 64)
-    Np = ceil_to(N, 256)
+    Np = max(ceil_to(N, 256), ceil_to(N, 320))  # readable by every block-tile variant (128/256/320-wide) without bounds checks
     wt = torch.zeros((Np, Kp), dtype=BF16, device=device)
     wt[:N, :K] = w2d.to(device=device, dtype=BF16)
     b = None
