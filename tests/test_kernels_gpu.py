@@ -340,9 +340,9 @@ def test_sampler_elementwise():
 
 
 # ------------------------------------------------------------------------------------------------ block-tile variants
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 10, 11, 12])
 def test_gemm_family_all_tile_configs(cfg):
-    """Every block-tile variant (128x128, 256x128, 256x256, 256x320) of every loader / epilogue, on shapes with ragged M and N edges."""
+    """Every block-tile variant (128x128, 256x128, 256x256, 256x320; +8 = register-staged instead of LDS-DMA) of every loader / epilogue, on shapes with ragged M and N edges."""
     ops = _ops()
     ops.TILE_CFG = cfg
     try:

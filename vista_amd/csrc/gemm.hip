@@ -31,7 +31,9 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
+__device__ uint4 g_zero16;  // source of the zero fill for out-of-image conv taps on the LDS-DMA path (zero-initialised)
+
+template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN, bool DMA>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc p) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;              // threads
@@ -62,10 +64,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
     const int lc = tid & 7;
     const int lr = tid >> 3;
     const int st_off = lds_off(lr, lc);  // (row>>1)&7 is invariant under +RPP*i (RPP is a multiple of 16)
+    // LDS-DMA (global_load_lds) writes lane l's 16 B at wave_base + 16*l, i.e. row lr, physical slot lc. To land the
+    // swizzled image (logical chunk c at slot c ^ ((row>>1)&7)) the lane must FETCH logical chunk lc ^ sw instead.
+    const int lsrc = DMA ? (lc ^ ((lr >> 1) & 7)) : lc;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const uint16_t* wptr[WP];
 #pragma unroll
-    for (int i = 0; i < WP; ++i) wptr[i] = Wg + (size_t)(n0 + lr + RPP * i) * p.K + lc * 8;
+    for (int i = 0; i < WP; ++i) wptr[i] = Wg + (size_t)(n0 + lr + RPP * i) * p.K + lsrc * 8;
 
     // A-row state
     const uint16_t* aptr[AP];
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         a_ok[i] = m < p.M;
         if (m >= p.M) m = p.M - 1;
         if (AMODE == AMODE_DENSE) {
-            aptr[i] = Ag + (size_t)m * p.lda + lc * 8;
+            aptr[i] = Ag + (size_t)m * p.lda + lsrc * 8;
             a_y0[i] = a_x0[i] = 0;
         } else if (AMODE == AMODE_CONV3X3) {
             const int hw = p.Hout * p.Wout;
@@ -86,12 +92,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
             a_y0[i] = oy * p.stride - 1;
             a_x0[i] = ox * p.stride - 1;
-            aptr[i] = Ag + (size_t)img * p.H * p.Wd * p.Cin + lc * 8;
+            aptr[i] = Ag + (size_t)img * p.H * p.Wd * p.Cin + lsrc * 8;
         } else {  // TEMPORAL3: m = (b*T + t)*S + s
             const int fr = m / p.S;
             a_y0[i] = fr % p.T;  // frame index t
             a_x0[i] = 0;
-            aptr[i] = Ag + (size_t)m * p.Cin + lc * 8;
+            aptr[i] = Ag + (size_t)m * p.Cin + lsrc * 8;
         }
     }
 
@@ -139,6 +145,46 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         for (int i = 0; i < WP; ++i) *(uint4*)(sW + st_off + i * RPP * 128) = rw[i];
     };
 
+    // direct global -> LDS staging of tile kt into `stage` (one 1-KiB global_load_lds_dwordx4 per wave and 8-row group)
+    auto dma_tile = [&](int kt, int stage) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int k0 = kt * BK;
+        char* sA = smem + stage * STAGE_BYTES + wave_u * 1024;
+        char* sW = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[i] + k0), (lptr_t)(sW + i * RPP * 128), 16, 0, 0);
+        if (AMODE == AMODE_DENSE) {
+#pragma unroll
+            for (int i = 0; i < AP; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + k0), (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+        } else if (AMODE == AMODE_CONV3X3) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int sh = p.ups - 1;
+            const int He = p.H << sh, We = p.Wd << sh;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                const bool ok = a_ok[i] && iy >= 0 && iy < He && ix >= 0 && ix < We;
+                const int sy = iy >> sh, sx = ix >> sh;
+                const uint16_t* src = ok ? aptr[i] + ((size_t)(sy * p.Wd + sx) * p.Cin + c0) : (const uint16_t*)&g_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+            }
+        } else {
+            const int dt = tap - 1;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int t = a_y0[i] + dt;
+                const bool ok = a_ok[i] && t >= 0 && t < p.T;
+                const uint16_t* src = ok ? aptr[i] + ((ptrdiff_t)dt * p.S * p.Cin + c0) : (const uint16_t*)&g_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+            }
+        }
+        c0 += BK;
+        if (c0 >= p.Cin) { c0 = 0; ++tap; }
+    };
+
     f32x16_t acc[FX][FY];
 #pragma unroll
     for (int i = 0; i < FX; ++i)
@@ -159,20 +205,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
     for (int ks = 0; ks < 4; ++ks) frag_off[ks] = ((ks * 2 + lh) ^ sw) << 4;
     const int xrow_off = (xoff + l31) * 128, yrow_off = (yoff + l31) * 128;
 
-    // Software pipeline: registers run TWO tiles ahead of the MFMAs, LDS one. In iteration kt the registers (tile kt+1,
-    // fetched during iteration kt-1) are written into the LDS stage that became free at the previous barrier while the
-    // MFMAs consume the other stage, and the global loads of tile kt+2 are issued right after -- so HBM/L2 latency is
-    // covered by a whole K-step and the LDS fill overlaps the matrix pipe instead of following it.
-    const int nk = p.K / BK;
-    load_tile(0);
-    store_tile(0);
-    if (nk > 1) load_tile(1);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < nk) store_tile(stage ^ 1);
-        if (kt + 2 < nk) load_tile(kt + 2);
+    auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -187,7 +220,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
                 for (int fj = 0; fj < FY; ++fj)
                     acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
         }
+    };
+    const int nk = p.K / BK;
+    if (DMA) {
+        // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
+        // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
+        dma_tile(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int stage = kt & 1;
+            if (kt + 1 < nk) dma_tile(kt + 1, stage ^ 1);
+            compute(stage);
+            __syncthreads();
+        }
+    } else {
+        // register-staged pipeline: prefetch tile kt+1 into VGPRs, compute tile kt, then write the VGPRs to the other stage
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int stage = kt & 1;
+            if (kt + 1 < nk) load_tile(kt + 1);
+            compute(stage);
+            if (kt + 1 < nk) store_tile(stage ^ 1);
+            __syncthreads();
+        }
     }
 
     // ------------------------------- epilogue -------------------------------
@@ -298,7 +355,10 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tilesN = (d->N + BN - 1) / BN;
     const int tilesM = (d->M + BM - 1) / BM;
-    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, *d);
+    if (d->tile_cfg & 8)  // register-staged variant (A/B testing)
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN, false>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, *d);
+    else
+        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN, true>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, *d);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
@@ -307,7 +367,7 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
 // to 256 wastes more than ~10% of the MFMA work, in which case 256x128.
 template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
-    const int force = d->tile_cfg;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (tests / tuning)
+    const int force = d->tile_cfg & 7;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (tests / tuning)
     int cfg = force;
     if (cfg == 4 && EPI == EPI_GEGLU) cfg = 3;  // the GEGLU packing needs 64-column wave tiles
     if (cfg == 0) {
@@ -331,7 +391,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || d->tile_cfg > 4) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 15) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;
