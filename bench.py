@@ -87,12 +87,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    dist = None
+    shard = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-        raise NotImplementedError("frame-sharded multi-GPU sampling lands with vista_amd/parallel (see DESIGN.md 'Multi-GPU'); "
-                                  "refusing to print a replica number under the frame-shard metric")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
     from vista_amd import _lib, ops, synth
     from vista_amd.modules.diffusionmodules.denoiser import Denoiser
     from vista_amd.modules.diffusionmodules.sampling import EulerEDMSampler, FusedDenoiser, FusedLoop
@@ -100,6 +100,9 @@ def main():
     _lib.load()
 
     T, H, W = args.frames, args.latent_h, args.latent_w
+    if world > 1:
+        from vista_amd.parallel import DistComm, FrameShard
+        shard = FrameShard(T, DistComm(), B=2)  # frames 25 -> 4/3/3/3/3/3/3/3 at 8 GPUs; pixel-sharded temporal halves
     net = build_model(args.model_channels)
     w = synth.window_inputs(T=T, H=H, W=W, seed=0)
     cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
@@ -111,29 +114,41 @@ def main():
     x, sigmas, _, cond, uc = sampler.prepare_sampling_loop(noise, cu(w["c"]), cu(w["uc"]))
     sig = [float(s) for s in sigmas]
     loop = FusedLoop(sampler, FusedDenoiser(den, OpenAIWrapper(net)), x.float().clone(), cond, uc, w["cond_frame"].cuda(),
-                     w["cond_mask"].cuda(), True, sig)
+                     w["cond_mask"].cuda(), True, sig, shard=shard)
     nsteps = len(sig) - 1
     assert args.warmup + args.steps <= nsteps, "at most 50 steps per window"
     for i in range(args.warmup):
         loop.step(i)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     ops.PROFILE_ATTN = []
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         loop.step(i)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if dist is not None:  # MAX over ranks
+        tdt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
     assert torch.isfinite(loop.xw).all(), "non-finite latents"
     ms_per_step = dt * 1e3 / args.steps
     value = args.steps / dt
 
     full = (T, H, W, args.model_channels) == (25, 72, 128, 320)
-    l0 = [e0.elapsed_time(e1) for (S, nbh, e0, e1) in prof if S == H * W]
+    l0 = [(e0.elapsed_time(e1), nbh) for (S, nbh, e0, e1) in prof if S == H * W]
     roofline = None
     if l0:
+        nbh = l0[0][1]  # (local images) x heads of this rank's level-0 launches
+        l0 = [t for t, _ in l0]
         avg_ms = sum(l0) / len(l0)
-        flop = 4.0 * (2 * T * (args.model_channels // 64)) * float(H * W) ** 2 * 64
+        flop = 4.0 * nbh * float(H * W) ** 2 * 64
         ach = flop / (avg_ms * 1e-3) / 1e12
         roofline = {"kernel": "attn_spatial_kernel (level-0 spatial self-attention)", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": None,
@@ -142,13 +157,16 @@ def main():
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": ("1xMI355X: 25x576x1024 (latent 25x4x72x128), 50-step EulerEDM, VanillaCFG 2.5 (N=50 images per UNet call), "
+        "config": {"workload": (f"{world}xMI355X" + (" frame-sharded " + "/".join(str(c) for c in shard.t_counts) if shard else "") +
+                                ": 25x576x1024 (latent 25x4x72x128), 50-step EulerEDM, VanillaCFG 2.5 (N=50 images per UNet call), "
                                 "bf16, random-init 1.65B VideoUNet, synthetic latents") if full else
                    f"REDUCED (not the BASELINE config): T={T} latent {H}x{W} model_channels={args.model_channels}",
                    "frames": T, "latent": [4, H, W], "cfg_images_per_call": 2 * T, "sampler": "EulerEDM s_churn=0, 50-step schedule",
-                   "windows_per_s": value / 50.0},
+                   "windows_per_s": value / 50.0,
+                   "parallelism": "single GPU" if shard is None else f"frame-shard x{world} (spatial half) + pixel-shard x{world} (temporal half), "
+                                  "2 RCCL all-to-alls per block pair, weights replicated"},
         "roofline": roofline,
-        "step_mfma_frac": (FLOP_PER_STEP_CFG / (ms_per_step * 1e-3) / MFMA_BF16_PEAK) if full else None,
+        "step_mfma_frac": (FLOP_PER_STEP_CFG / (ms_per_step * 1e-3) / (MFMA_BF16_PEAK * world)) if full else None,
     }
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         h, wd = (int(v) for v in args.cpu_sample.split("x"))
@@ -157,6 +175,9 @@ def main():
         res["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

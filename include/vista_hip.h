@@ -75,6 +75,14 @@ int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const flo
                            int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group, float eps, int32_t silu,
                            void* stream);
 
+/* The two halves of vk_groupnorm_silu_bf16, for pixel-sharded multi-GPU runs of the temporal ResBlock: `sums` is
+ * [n_img/frames_per_group][64] = raw [32 sums | 32 sums of squares] over the LOCAL elements (all-reduce them across ranks),
+ * `partial_ws` needs 64*n_img*ceil(S/128) floats, `count` is the GLOBAL element count per (image-group, channel-group). */
+int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C,
+                            int32_t frames_per_group, void* stream);
+int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img,
+                            int32_t S, int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream);
+
 /* LayerNorm over C of x[rows][C] (+ optional per-image pre-add vector):  u = x + addvec[row / rows_per_vec];
  * if sum_out: sum_out = u (bf16);  y = LN(u)*gamma + beta.
  * Replaces nn.LayerNorm at attention.py:514-524 (norm1-3) and video_attention.py:119-137 (norm_in, norm1-3),

@@ -1,0 +1,77 @@
+"""Multi-GPU partition / exchange logic of vista_amd.parallel on CPU: in-process thread ranks and real 2-process gloo.
+(The sharded numerics of the whole UNet are validated on the GPU box with thread ranks: tests/test_parallel_gpu.py.)"""
+import os
+import threading
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vista_amd.parallel import DistComm, FrameShard, ThreadComm, offsets, split_counts
+
+
+def test_split_counts_matches_baseline_partition():
+    assert split_counts(25, 8) == [4, 3, 3, 3, 3, 3, 3, 3]  # BASELINE.json config 3
+    assert split_counts(25, 4) == [7, 6, 6, 6] and split_counts(25, 2) == [13, 12] and split_counts(25, 1) == [25]
+    assert offsets([4, 3, 3]) == [0, 4, 7, 10]
+    with pytest.raises(ValueError):
+        FrameShard(3, type("C", (), {"world": 4, "rank": 0})())
+
+
+def _check_rank(shard, X):
+    """X: the global (B, T, S, C) tensor, identical on all ranks."""
+    B, T, S, C = X.shape
+    r, P = shard.rank, shard.P
+    t0, t1 = shard.t_off[r], shard.t_off[r + 1]
+    x_f = X[:, t0:t1].reshape(B * (t1 - t0), S, C).contiguous()
+    so = offsets(shard.pixel_counts(S))
+    x_p = shard.to_pixels(x_f)
+    assert torch.equal(x_p, X[:, :, so[r]:so[r + 1]].reshape(B * T, -1, C)), "to_pixels must yield all frames of the rank's pixel slice"
+    back = shard.to_frames(x_p, S)
+    assert torch.equal(back, x_f), "to_frames(to_pixels(x)) must be the identity"
+    s = torch.full((4,), float(r + 1))
+    shard.all_reduce_sum(s)
+    assert torch.equal(s, torch.full((4,), float(P * (P + 1) // 2)))
+    full = torch.arange(B * T).float()[:, None].repeat(1, 3)
+    loc = shard.take_local_rows(full)
+    assert loc[:, 0].tolist() == [float(b * T + t) for b in range(B) for t in range(t0, t1)]
+    g = shard.gather_frames(X[0, t0:t1, :, 0].contiguous())
+    assert torch.equal(g, X[0, :, :, 0])
+
+
+@pytest.mark.parametrize("P,T,S", [(2, 5, 16), (3, 7, 10), (8, 25, 144), (4, 25, 18)])
+def test_frame_pixel_exchange_thread_ranks(P, T, S):
+    B, C = 2, 8
+    X = torch.randn(B, T, S, C)
+    shared = ThreadComm.Shared(P)
+    errs = []
+
+    def run(rank):
+        try:
+            _check_rank(FrameShard(T, ThreadComm(shared, rank), B=B), X)
+        except Exception as e:  # noqa: BLE001
+            errs.append((rank, repr(e)))
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+
+
+def _gloo_worker(rank, world, port, T, S):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        X = torch.randn(2, T, S, 8)
+        _check_rank(FrameShard(T, DistComm(), B=2), X)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_pixel_exchange_gloo_two_processes():
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, 5, 16), nprocs=2, join=True)

@@ -1,0 +1,41 @@
+"""Summarise a rocprofv3 results DB (rocpd sqlite) into a per-kernel table (the `--stats` view) as text.
+Usage: python tools/prof_summary.py <results.db> [header text] > profiles/xxx.txt"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    if "gemm_kernel" in name:
+        m = re.search(r"gemm_kernel<([^>]*)>", name)
+        a = [x.strip() for x in m.group(1).split(",")]
+        am = {"0": "dense", "1": "conv3x3", "2": "temporal3"}[a[0]]
+        ep = {"0": "linear", "1": "geglu", "2": "trans"}[a[1]]
+        tile = f"{int(a[3])*int(a[5])*32}x{int(a[4])*int(a[6])*32}" if len(a) >= 7 else "128x128"
+        dma = (" dma" if a[7] == "true" else " reg") if len(a) >= 8 else ""
+        return f"gemm_kernel[{am},{ep},{'f32' if a[2]=='true' else 'bf16'},{tile}{dma}]"
+    if "at::native" in name or "rocclr" in name:
+        m = re.search(r"(\w+_kernel\w*|__amd_rocclr_\w+)", name)
+        return "torch/runtime: " + (m.group(1) if m else name[:40])
+    m = re.search(r"(\w+_kernel(?:<\d+>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
+    agg = {}
+    for n, c, t, a, p in rows:
+        k = short(n)
+        e = agg.setdefault(k, [0, 0.0, 0.0])
+        e[0] += c; e[1] += t; e[2] += p
+    if len(sys.argv) > 2:
+        print(sys.argv[2])
+    print(f"{'kernel':62s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for k, (c, t, p) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"{k:62s} {c:7d} {t/1e3:10.2f} {t/c:10.2f} {p:6.2f}")
+    print(f"{'TOTAL':62s} {sum(v[0] for v in agg.values()):7d} {sum(v[1] for v in agg.values())/1e3:10.2f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -65,8 +65,9 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restric
 }
 
 // stats pass 2: one workgroup per image-group; sums the (frames_per_group x chunks) partials of each of the 64 values
-// in a fixed order (4 strided lanes per value, then a fixed 4-way combine) and writes mean / rstd.
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int nparts, float inv_cnt, float eps) {
+// in a fixed order (4 strided lanes per value, then a fixed 4-way combine) and writes the raw [32 sums | 32 sums of squares]
+// (kept raw so that a pixel-sharded multi-GPU run can all-reduce them before the apply pass).
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nparts) {
     __shared__ float red[4][64];
     const int v = threadIdx.x & 63, j = threadIdx.x >> 6;  // 256 threads
     const float* src = partial + (size_t)blockIdx.x * nparts * 64 + v;
@@ -74,20 +75,12 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __r
     for (int i = j; i < nparts; i += 4) a += src[(size_t)i * 64];
     red[j][v] = a;
     __syncthreads();
-    if (threadIdx.x < 32) {
-        const int g = threadIdx.x;
-        const float sum = (red[0][g] + red[1][g]) + (red[2][g] + red[3][g]);
-        const float sq = (red[0][32 + g] + red[1][32 + g]) + (red[2][32 + g] + red[3][32 + g]);
-        const float mean = sum * inv_cnt;
-        const float var = fmaxf(sq * inv_cnt - mean * mean, 0.f);
-        stats[(size_t)blockIdx.x * 64 + g] = mean;
-        stats[(size_t)blockIdx.x * 64 + 32 + g] = rsqrtf(var + eps);
-    }
+    if (threadIdx.x < 64) sums[(size_t)blockIdx.x * 64 + v] = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
 }
 
 __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ stats, int S, int C, int CG, int R,
-                                int frames_per_group, float eps, int do_silu) {
+                                int frames_per_group, float inv_cnt, float eps, int do_silu) {
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
     const int tok0 = blockIdx.x * GN_TOK;
@@ -95,14 +88,16 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
     const int chunk = tid % CG, r = tid / CG;
     if (r >= R) return;
     const int cpg = C >> 5;
-    const float* st = stats + (size_t)(img / frames_per_group) * 64;  // [32 means | 32 rstds]
+    const float* st = stats + (size_t)(img / frames_per_group) * 64;  // [32 sums | 32 sums of squares]
     float a[8], b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = chunk * 8 + e;
         const int g = c / cpg;
-        a[e] = gamma[c] * st[32 + g];
-        b[e] = beta[c] - st[g] * a[e];
+        const float mean = st[g] * inv_cnt;
+        const float var = fmaxf(st[32 + g] * inv_cnt - mean * mean, 0.f);
+        a[e] = gamma[c] * rsqrtf(var + eps);
+        b[e] = beta[c] - mean * a[e];
     }
     const size_t base = ((size_t)img * S) * C + chunk * 8;
     for (int t = tok0 + r; t < tok1; t += R) {
@@ -190,33 +185,57 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 
 }  // namespace
 
-extern "C" int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws, int32_t n_img,
-                                      int32_t S, int32_t C, int32_t frames_per_group, float eps, int32_t silu, void* stream_) {
+namespace {
+struct GnGeom { int CG, R, threads, nchunks, ngroups; };
+inline bool gn_geom(int n_img, int S, int C, int fpg, GnGeom& g) {
+    if (n_img <= 0 || S <= 0 || C <= 0 || (C % 32) != 0 || (C % 8) != 0 || C > 8192) return false;
+    if (fpg <= 0 || (n_img % fpg) != 0) return false;
+    g.CG = C / 8;
+    if (g.CG > 1024) return false;
+    g.R = 256 / g.CG;
+    if (g.R < 1) g.R = 1;
+    g.threads = ((g.CG * g.R + 63) / 64) * 64;
+    g.nchunks = (S + GN_TOK - 1) / GN_TOK;
+    g.ngroups = n_img / fpg;
+    return true;
+}
+}  // namespace
+
+extern "C" int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C,
+                                       int32_t frames_per_group, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!x || !y || !gamma || !beta || !stats_ws) return VK_EINVAL;
-    if (n_img <= 0 || S <= 0 || C <= 0 || (C % 32) != 0 || (C % 8) != 0 || C > 8192) return VK_EINVAL;
-    if (frames_per_group <= 0 || (n_img % frames_per_group) != 0) return VK_EINVAL;
-    const int CG = C / 8;
-    if (CG > 1024) return VK_EINVAL;
-    int R = 256 / CG;
-    if (R < 1) R = 1;
-    const int threads = ((CG * R + 63) / 64) * 64;
-    // workspace: [n_img/fpg][64] mean|rstd, then [n_img][chunks][64] partial sums
-    const int nchunks = (S + GN_TOK - 1) / GN_TOK;
-    const int ngroups = n_img / frames_per_group;
-    float* partial = stats_ws + (size_t)ngroups * 64;
-    dim3 grid(nchunks, n_img);
-    const size_t lds_bytes = (size_t)2 * R * C * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(threads), lds_bytes, stream, (const uint16_t*)x, partial, S, C, CG, R);
+    GnGeom g;
+    if (!x || !sums || !partial_ws || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
+    dim3 grid(g.nchunks, n_img);
+    const size_t lds_bytes = (size_t)2 * g.R * C * sizeof(float);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, partial_ws, S, C, g.CG, g.R);
     VK_CHECK_LAUNCH();
-    const float inv_cnt = 1.f / ((float)(C / 32) * (float)S * (float)frames_per_group);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(ngroups), dim3(256), 0, stream, (const float*)partial, stats_ws,
-                       frames_per_group * nchunks, inv_cnt, eps);
-    VK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(threads), 0, stream, (const uint16_t*)x, (uint16_t*)y, gamma, beta,
-                       (const float*)stats_ws, S, C, CG, R, frames_per_group, eps, silu);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(g.ngroups), dim3(256), 0, stream, (const float*)partial_ws, sums, frames_per_group * g.nchunks);
     VK_CHECK_LAUNCH();
     return VK_OK;
+}
+
+extern "C" int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img,
+                                       int32_t S, int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    GnGeom g;
+    if (!x || !y || !gamma || !beta || !sums || count <= 0.f || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
+    dim3 grid(g.nchunks, n_img);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (uint16_t*)y, gamma, beta, sums, S, C, g.CG, g.R,
+                       frames_per_group, 1.f / count, eps, silu);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
+extern "C" int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws, int32_t n_img,
+                                      int32_t S, int32_t C, int32_t frames_per_group, float eps, int32_t silu, void* stream_) {
+    if (!stats_ws || frames_per_group <= 0 || n_img <= 0) return VK_EINVAL;
+    // workspace: [n_img/fpg][64] sums, then [n_img][chunks][64] partial sums
+    float* partial = stats_ws + (size_t)(n_img / frames_per_group) * 64;
+    int rc = vk_groupnorm_stats_bf16(x, stats_ws, partial, n_img, S, C, frames_per_group, stream_);
+    if (rc != VK_OK) return rc;
+    const float count = (float)(C / 32) * (float)S * (float)frames_per_group;
+    return vk_groupnorm_apply_bf16(x, y, gamma, beta, stats_ws, n_img, S, C, frames_per_group, count, eps, silu, stream_);
 }
 
 extern "C" int vk_layernorm_bf16(const void* x, void* y, void* sum_out, const float* gamma, const float* beta, const float* addvec,

@@ -23,14 +23,16 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """openaimodel.py:27-53: passes (emb | context | num_frames) to the children that take them.
     Activations are token-major: x (n_img, S, C) bf16 with the spatial size (H, W) carried alongside."""
 
-    def forward(self, x, emb_silu, context=None, frame_idx=None, num_frames=None, H=None, W=None):
+    def forward(self, x, emb_silu, context=None, frame_idx=None, num_frames=None, H=None, W=None, shard=None, full=None):
+        """shard / full: multi-GPU frame sharding (vista_amd.parallel.FrameShard) and the replicated full-window
+        tensors {"emb_silu": (B*T, E), "ctx": (B*T, ctx)} the pixel-sharded temporal halves need."""
         from ..video_attention import SpatialVideoTransformer
         from .video_model import VideoResBlock
         for layer in self:
             if isinstance(layer, VideoResBlock):
-                x = layer(x, emb_silu, num_frames, H, W)
+                x = layer(x, emb_silu, num_frames, H, W, shard=shard, full=full)
             elif isinstance(layer, SpatialVideoTransformer):
-                x = layer(x, context, frame_idx, num_frames, H, W)
+                x = layer(x, context, frame_idx, num_frames, H, W, shard=shard, full=full)
             elif isinstance(layer, (Upsample, Downsample)):
                 x, H, W = layer(x, H, W)
             else:
@@ -117,7 +119,7 @@ class ResBlock(TimestepBlock, Packable):
             pk["skip"] = ops.pack_linear(self.skip_connection.weight, self.skip_connection.bias, dev)
         return pk
 
-    def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, blend=None):
+    def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, shard=None, S_total=None):
         """x (n_img, S, C) bf16; emb_silu (n_img, emb_channels) bf16 = silu(emb).
         dims=2: returns skip(x) + h.  dims=3 (time_stack): statistics/conv span the T frames of each clip and the result is
         blend + out_alpha*(conv2 + bias) with blend = x, i.e. AlphaBlender(x_spatial=x, x_temporal=x+h) folded in."""
@@ -126,7 +128,14 @@ class ResBlock(TimestepBlock, Packable):
         gn1, gn2 = self.in_layers[0], self.out_layers[0]
         fpg = 1 if self.dims == 2 else T
         emb_out = ops.linear(emb_silu, pk["emb"], out_f32=True)  # (n_img, Cout): `emb_layers(emb)[..., None, None]`
-        h = ops.groupnorm(x, gn1.weight, gn1.bias, gn1.eps, silu=True, frames_per_group=fpg)
+
+        def gnorm(t, gn):
+            if shard is None or self.dims == 2:
+                return ops.groupnorm(t, gn.weight, gn.bias, gn.eps, silu=True, frames_per_group=fpg)
+            # pixel-sharded temporal norm: statistics span (C/32, T, all H*W pixels) -> all-reduce the partial sums
+            cnt = float(t.shape[-1] // 32) * float(S_total) * float(T)
+            return ops.groupnorm_sharded(t, gn.weight, gn.bias, gn.eps, True, fpg, shard.all_reduce_sum, cnt)
+        h = gnorm(x, gn1)
         if self.dims == 2:
             h, _, _ = ops.conv3x3(h, pk["conv1"], n_img, H, W, rowvec=emb_out)
             h = ops.groupnorm(h, gn2.weight, gn2.bias, gn2.eps, silu=True)
@@ -134,7 +143,7 @@ class ResBlock(TimestepBlock, Packable):
             out, _, _ = ops.conv3x3(h, pk["conv2"], n_img, H, W, res1=skip)
             return out
         h = ops.conv_t3(h, pk["conv1"], T, S, rowvec=emb_out)
-        h = ops.groupnorm(h, gn2.weight, gn2.bias, gn2.eps, silu=True, frames_per_group=fpg)
+        h = gnorm(h, gn2)
         return ops.conv_t3(h, pk["conv2"], T, S, alpha=out_alpha, res2=x, beta=1.0)
 
 

@@ -104,7 +104,9 @@ class EulerEDMSampler(SingleStepDiffusionSampler):
 
     # ---- fused path ---------------------------------------------------------------------------------------------
     def _sample_fused(self, fd, x, cond, uc, cond_frame, maskf, replace, sig):
-        loop = FusedLoop(self, fd, x.float().clone(), cond, uc, cond_frame, maskf, replace, sig)
+        """`self.shard` (a vista_amd.parallel.FrameShard, set by the caller on every rank) turns on frame sharding: every
+        rank passes the same full-window tensors, works on its own frames and returns the gathered full result."""
+        loop = FusedLoop(self, fd, x.float().clone(), cond, uc, cond_frame, maskf, replace, sig, shard=getattr(self, "shard", None))
         for i in range(len(sig) - 1):
             loop.step(i)
         return loop.finish().to(x.dtype)
@@ -114,15 +116,19 @@ class FusedLoop:
     """State of one fused sampling run; `step(i)` is exactly one EulerEDMSampler.sampler_step (sampling.py:78-89):
     mask replace -> CFG-doubled UNet forward -> guider combine -> to_d -> Euler update. bench.py times this."""
 
-    def __init__(self, sampler, fd, xw, cond, uc, cond_frame, maskf, replace, sig):
+    def __init__(self, sampler, fd, xw, cond, uc, cond_frame, maskf, replace, sig, shard=None):
         from .video_model import CIN_PAD
         self.cin_pad = CIN_PAD
         self.den, self.unet = fd.denoiser, fd.network.diffusion_model
-        self.xw, self.sig, self.replace, self.maskf = xw, sig, replace, maskf
+        self.sig, self.replace, self.shard = sig, replace, shard
         n, _, self.H, self.W = xw.shape
         self.n, self.T = n, self.den.num_frames
         T, dev = self.T, xw.device
-        self.scales = sampler.guider.frame_scales(T).float().repeat(n // T).to(dev)
+        scales = sampler.guider.frame_scales(T).float().repeat(n // T).to(dev)
+        if shard is not None and n != T:
+            raise NotImplementedError("frame sharding handles one window (b = 1) per call")
+        loc = (lambda t: t) if shard is None else (lambda t: shard.take_local_frames(t).contiguous())
+        self.xw, self.maskf, self.scales = loc(xw), loc(maskf), loc(scales)
 
         def both(k):
             a, b = uc[k], cond[k]
@@ -130,11 +136,11 @@ class FusedLoop:
                 a, b = a.repeat_interleave(T, 0), b.repeat_interleave(T, 0)
             return a, b
         cu, cc = both("concat")
-        self.cu, self.cc = cu.float().contiguous(), cc.float().contiguous()
-        self.ctx2 = torch.cat(both("crossattn"), 0)
+        self.cu, self.cc = loc(cu.float().contiguous()), loc(cc.float().contiguous())
+        self.ctx2 = torch.cat(both("crossattn"), 0)   # full window (replicated on every rank)
         self.y2 = torch.cat(both("vector"), 0)
         self.mask2 = torch.cat([maskf, maskf])
-        self.cf = cond_frame.float().contiguous() if replace else None
+        self.cf = loc(cond_frame.float().contiguous()) if replace else None
         # EDM coefficients per step on the host (denoiser_scaling.py:51-59): no device round trip inside the loop
         self.coef = [tuple(float(v) for v in self.den.scaling(torch.tensor(s, dtype=torch.float32))) for s in sig[:-1]]
 
@@ -142,10 +148,10 @@ class FusedLoop:
         c_skip, c_out, c_in, c_noise = self.coef[i]
         net_in = ops.sampler_prepare(self.xw, self.cf, self.maskf, self.cu, self.cc, self.cin_pad, c_in, self.replace)
         ts = torch.full((2 * self.n,), c_noise, device=self.xw.device)
-        net_out = self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W)
+        net_out = self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.shard)
         ops.sampler_update(self.xw, net_out, self.scales, c_out, c_skip, self.sig[i], self.sig[i + 1])
 
     def finish(self):
         if self.replace:
             self.xw = ops.mask_replace(self.xw, self.cf, self.maskf)
-        return self.xw
+        return self.xw if self.shard is None else self.shard.gather_frames(self.xw)

@@ -38,12 +38,17 @@ class VideoResBlock(ResBlock):
         super().invalidate_packed()
         self._alpha = None
 
-    def forward(self, x, emb_silu, num_frames, H, W):
+    def forward(self, x, emb_silu, num_frames, H, W, shard=None, full=None):
         x = super().forward(x, emb_silu, H, W)
         if self._alpha is None:
             self._alpha = self.time_mixer.alpha_value()
         # alpha*x + (1-alpha)*(x + h_t) == x + (1-alpha)*h_t, fused into the last temporal conv's epilogue
-        return self.time_stack(x, emb_silu, H, W, T=num_frames, out_alpha=1.0 - self._alpha)
+        if shard is None:
+            return self.time_stack(x, emb_silu, H, W, T=num_frames, out_alpha=1.0 - self._alpha)
+        S = x.shape[1]
+        xp = shard.to_pixels(x)  # (B*T, S_r, C): all frames of this rank's pixels
+        yp = self.time_stack(xp, full["emb_silu"], H, W, T=num_frames, out_alpha=1.0 - self._alpha, shard=shard, S_total=S)
+        return shard.to_frames(yp, S)
 
 
 class VideoUNet(nn.Module, Packable):
@@ -231,11 +236,12 @@ class VideoUNet(nn.Module, Packable):
         return ops.tokens_to_nchw(out_tok, n_img, self.out_channels, H, W).to(x.dtype)
 
     @torch.no_grad()
-    def forward_tokens(self, tokens, timesteps, context, y, cond_mask, T, H, W):
+    def forward_tokens(self, tokens, timesteps, context, y, cond_mask, T, H, W, shard=None):
         """Token-major entry used by the fused sampler path: tokens (N, H*W, 64) bf16 (channels >= in_channels zero);
-        returns (N, H*W, out_channels) f32."""
+        returns (N, H*W, out_channels) f32. With `shard` (vista_amd.parallel.FrameShard) `tokens` holds only this rank's
+        frames ((b, t_local) order) while timesteps / context / y / cond_mask are the replicated full-window tensors."""
         pk = self.packed()
-        n_img = tokens.shape[0]
+        n_img = timesteps.shape[0]  # images of the full window (B*T)
         dev = tokens.device
         t_emb = timestep_embedding(timesteps, self.model_channels, max_period=10000)
         te = mlp_f32(t_emb, *pk["time_embed"])
@@ -257,19 +263,25 @@ class VideoUNet(nn.Module, Packable):
             raise NotImplementedError("Vista's cross-attention context is one token per image (crossattn: (N, 1, 3456))")
         ctx = ops.cast_to_bf16(context.float().reshape(n_img, -1))
         frame_idx = self._frame_idx(n_img, T, dev)
+        full = None
+        if shard is not None:  # spatial halves see this rank's rows; temporal halves get the replicated full tensors
+            full = {"emb_silu": emb_silu, "ctx": ctx}
+            emb_silu = shard.take_local_rows(emb_silu)
+            ctx = shard.take_local_rows(ctx)
+        kw = dict(frame_idx=frame_idx, num_frames=T, shard=shard, full=full)
 
         hs = []
         h = tokens
         for module in self.input_blocks:
-            h, H, W = module(h, emb_silu, context=ctx, frame_idx=frame_idx, num_frames=T, H=H, W=W)
+            h, H, W = module(h, emb_silu, context=ctx, H=H, W=W, **kw)
             hs.append(h)
-        h, H, W = self.middle_block(h, emb_silu, context=ctx, frame_idx=frame_idx, num_frames=T, H=H, W=W)
+        h, H, W = self.middle_block(h, emb_silu, context=ctx, H=H, W=W, **kw)
         for module in self.output_blocks:
             h = ops.concat_channels(h, hs.pop())
-            h, H, W = module(h, emb_silu, context=ctx, frame_idx=frame_idx, num_frames=T, H=H, W=W)
+            h, H, W = module(h, emb_silu, context=ctx, H=H, W=W, **kw)
         gn = self.out[0]
         h = ops.groupnorm(h, gn.weight, gn.bias, gn.eps, silu=True)
-        out, _, _ = ops.conv3x3(h, pk["out"], n_img, H, W, out_f32=True)
+        out, _, _ = ops.conv3x3(h, pk["out"], tokens.shape[0], H, W, out_f32=True)
         return out
 
 
@@ -282,6 +294,6 @@ class _InputConv(TimestepEmbedSequential, Packable):
     def _pack(self, dev):
         return ops.pack_conv3x3(self[0].weight, self[0].bias, cin_pad=CIN_PAD, device=dev)
 
-    def forward(self, x, emb_silu, context=None, frame_idx=None, num_frames=None, H=None, W=None):
+    def forward(self, x, emb_silu, context=None, frame_idx=None, num_frames=None, H=None, W=None, shard=None, full=None):
         out, H, W = ops.conv3x3(x, self.packed(), x.shape[0], H, W)
         return out, H, W

@@ -116,19 +116,29 @@ class SpatialVideoTransformer(SpatialTransformer):
                 "tpe2": ops.pack_linear(self.time_pos_embed[2].weight, self.time_pos_embed[2].bias, dev),
                 "alpha": self.time_mixer.alpha_value()}
 
-    def forward(self, x, context, frame_idx, T, H, W):
-        """x: (n_img, S, C) bf16 tokens; context: (n_img, ctx_width) bf16 (one token per image); frame_idx: (n_img,) f32
-        frame index of every image (arange(T) repeated per clip, video_attention.py:270-271)."""
+    def forward(self, x, context, frame_idx, T, H, W, shard=None, full=None):
+        """x: (n_img, S, C) bf16 tokens; context: (n_img, ctx_width) bf16 (one token per image); frame_idx: (B*T,) f32 frame
+        index of every image of the window (arange(T) repeated per clip, video_attention.py:270-271).
+        Multi-GPU (`shard`): x / context hold this rank's frames; the temporal block runs pixel-sharded between two
+        all-to-alls and uses the replicated full["ctx"] for the clips' first-frame context."""
         pk = self.packed()
         n_img, S, C = x.shape
-        B = n_img // T
         x_in = x
         h = ops.groupnorm(x, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
         h = ops.linear(h, pk["proj_in"])                                           # (n_img*S, C)
         emb = mlp_f32(timestep_embedding(frame_idx, self.in_channels, self.max_time_embed_period), pk["tpe0"], pk["tpe2"])
-        clip_context = context.view(B, T, -1)[:, 0]                                # context[::T] (first frame of each clip)
+        ctx_full = context if shard is None else full["ctx"]
+        B = ctx_full.shape[0] // T
+        clip_context = ctx_full.view(B, T, -1)[:, 0]                               # context[::T] (first frame of each clip)
         for block, mix_block in zip(self.transformer_blocks, self.time_stack):
             h = block(h, context, n_img, S)
-            h = mix_block(h, emb, clip_context, B, T, S, blend_with=h, alpha=pk["alpha"])
+            if shard is None:
+                h = mix_block(h, emb, clip_context, B, T, S, blend_with=h, alpha=pk["alpha"])
+            else:
+                hp = shard.to_pixels(h.view(n_img, S, C))                          # (B*T, S_r, C)
+                s_r = hp.shape[1]
+                hp = hp.view(-1, C)
+                hp = mix_block(hp, emb, clip_context, B, T, s_r, blend_with=hp, alpha=pk["alpha"])
+                h = shard.to_frames(hp.view(B * T, s_r, C), S).view(-1, C)
         out = ops.linear(h, pk["proj_out"], res1=x_in)
         return out.view(n_img, S, C)

@@ -273,6 +273,23 @@ def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None):
     return out
 
 
+def groupnorm_sharded(x, gamma, beta, eps, silu, frames_per_group, allreduce, global_count):
+    """GroupNorm whose statistics also span other ranks' shards of the same images (pixel-sharded temporal ResBlock):
+    local fixed-order sums -> `allreduce(sums)` (in place, SUM over ranks) -> apply with the GLOBAL element count."""
+    _need(x, BF16, "x")
+    n_img, S, Cc = x.shape
+    out = torch.empty_like(x)
+    ng = n_img // frames_per_group
+    sums = torch.empty(ng * 64, dtype=F32, device=x.device)
+    part = torch.empty(n_img * ((S + 127) // 128) * 64, dtype=F32, device=x.device)
+    lib = _lib.load()
+    check(lib.vk_groupnorm_stats_bf16(_p(x), _p(sums), _p(part), n_img, S, Cc, frames_per_group, _stream()), "vk_groupnorm_stats_bf16")
+    allreduce(sums)
+    check(lib.vk_groupnorm_apply_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(sums), n_img, S, Cc, frames_per_group, float(global_count),
+                                      float(eps), 1 if silu else 0, _stream()), "vk_groupnorm_apply_bf16")
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5, addvec=None, rows_per_vec=0, want_sum=False):
     """x (..., C) bf16 contiguous -> LN(x + addvec[row // rows_per_vec]); optionally also returns the sum."""
     _need(x, BF16, "x")

@@ -1,0 +1,185 @@
+"""Frame-sharded multi-GPU execution of the denoising step (one process per GPU, RCCL over xGMI).
+
+The reference has no multi-GPU inference path. Frames of the 25-frame window couple in three places per block pair
+(temporal self-attention, the 3x1x1 temporal convs and the 5-D GroupNorms of every VideoResBlock.time_stack), so a
+single all-gather is not enough. The partition used here:
+
+  spatial half  (2-D ResBlock, spatial transformer block, up/down-sampling, per-image norms, sampler elementwise):
+      FRAME-sharded -- rank r owns t_r frames (of both CFG halves), all pixels.           25 -> 4/3/3/3/3/3/3/3 at 8 GPUs
+  temporal half (time_stack ResBlock, VideoTransformerBlock): every op is pointwise in space, so it runs
+      PIXEL-sharded -- rank r owns all T frames of S/P pixels.
+
+`to_pixels` / `to_frames` re-shard with ONE all-to-all each (xGMI is point-to-point: every pair of GPUs exchanges its
+slice directly, all 7 links busy, no ring). The only other collective is a 64-float-per-clip all-reduce of the 5-D
+GroupNorm partial sums. Weights and the (tiny) conditioning tensors are replicated. No collective touches the spatial
+half.
+
+Communicators: `DistComm` wraps torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests);
+`ThreadComm` runs P ranks as threads of one process (used to validate the sharded numerics on a single GPU).
+"""
+import threading
+
+import torch
+
+
+def split_counts(n, parts):
+    """n items over `parts` ranks, larger shares first: 25 over 8 -> [4,3,3,3,3,3,3,3]."""
+    base, rem = divmod(n, parts)
+    return [base + (1 if r < rem else 0) for r in range(parts)]
+
+
+def offsets(counts):
+    o = [0]
+    for c in counts:
+        o.append(o[-1] + c)
+    return o
+
+
+class DistComm:
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+
+    def all_to_all(self, recv, send, out_splits, in_splits):
+        self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+
+    def all_reduce_sum(self, t):
+        self.dist.all_reduce(t, group=self.group)
+
+    def all_gather_list(self, t, counts):
+        mx = max(counts)  # pad to equal sizes: uneven all_gather is not portable across backends
+        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        outs = [torch.empty_like(pad) for _ in counts]
+        self.dist.all_gather(outs, pad, group=self.group)
+        return [o[:c] for o, c in zip(outs, counts)]
+
+
+class ThreadComm:
+    """In-process emulation: P threads, one per rank, exchange through shared slots guarded by a barrier."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.world = shared, rank, shared.world
+
+    def _exchange(self, payload):
+        sh = self.shared
+        sh.slots[self.rank] = payload
+        t = payload[0] if isinstance(payload, tuple) else payload
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        sh.barrier.wait()
+        got = list(sh.slots)
+        sh.barrier.wait()
+        return got
+
+    def all_to_all(self, recv, send, out_splits, in_splits):
+        got = self._exchange((send, in_splits))
+        pos = 0
+        for q in range(self.world):
+            s_q, splits_q = got[q]
+            o = offsets(splits_q)
+            chunk = s_q[o[self.rank]:o[self.rank + 1]]
+            assert chunk.numel() == out_splits[q]
+            recv[pos:pos + out_splits[q]].copy_(chunk)
+            pos += out_splits[q]
+        if recv.is_cuda:
+            torch.cuda.synchronize()
+        self.shared.barrier.wait()
+
+    def all_reduce_sum(self, t):
+        got = self._exchange(t.clone())
+        acc = got[0].clone()
+        for q in range(1, self.world):  # fixed order: every rank computes the identical sum
+            acc += got[q]
+        t.copy_(acc)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        self.shared.barrier.wait()
+
+    def all_gather_list(self, t, counts):
+        got = self._exchange(t.clone())
+        return [g.clone() for g in got]
+
+
+class FrameShard:
+    """Frame / pixel partition of one sampling window and the exchanges between the two layouts."""
+
+    def __init__(self, T, comm, B=2):
+        self.T, self.comm, self.B = T, comm, B
+        self.P, self.rank = comm.world, comm.rank
+        if self.P > T:
+            raise ValueError(f"cannot shard {T} frames over {self.P} ranks")
+        self.t_counts = split_counts(T, self.P)
+        self.t_off = offsets(self.t_counts)
+        self.t_local = self.t_counts[self.rank]
+
+    # global image ids (b*T + t) of this rank's frames, in local (b, t_local) order
+    def local_image_ids(self):
+        t0 = self.t_off[self.rank]
+        return [b * self.T + t0 + i for b in range(self.B) for i in range(self.t_local)]
+
+    def pixel_counts(self, S):
+        return split_counts(S, self.P)
+
+    def to_pixels(self, x):
+        """(B*t_local, S, C) frame-sharded -> (B*T, S_r, C) pixel-sharded (frames in global order)."""
+        B, P, r = self.B, self.P, self.rank
+        n, S, C = x.shape
+        t_l = self.t_local
+        assert n == B * t_l
+        sc = self.pixel_counts(S)
+        so = offsets(sc)
+        x4 = x.view(B, t_l, S, C)
+        send = torch.cat([x4[:, :, so[q]:so[q + 1]].reshape(-1) for q in range(P)])
+        in_splits = [B * t_l * sc[q] * C for q in range(P)]
+        out_splits = [B * self.t_counts[q] * sc[r] * C for q in range(P)]
+        recv = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
+        self.comm.all_to_all(recv, send, out_splits, in_splits)
+        out = torch.empty((B, self.T, sc[r], C), dtype=x.dtype, device=x.device)
+        ro = offsets(out_splits)
+        for q in range(P):
+            out[:, self.t_off[q]:self.t_off[q + 1]] = recv[ro[q]:ro[q + 1]].view(B, self.t_counts[q], sc[r], C)
+        return out.view(B * self.T, sc[r], C)
+
+    def to_frames(self, y, S):
+        """(B*T, S_r, C) pixel-sharded -> (B*t_local, S, C) frame-sharded."""
+        B, P, r = self.B, self.P, self.rank
+        n, s_r, C = y.shape
+        assert n == B * self.T
+        sc = self.pixel_counts(S)
+        so = offsets(sc)
+        assert s_r == sc[r]
+        y4 = y.view(B, self.T, s_r, C)
+        send = torch.cat([y4[:, self.t_off[q]:self.t_off[q + 1]].reshape(-1) for q in range(P)])
+        in_splits = [B * self.t_counts[q] * s_r * C for q in range(P)]
+        out_splits = [B * self.t_local * sc[q] * C for q in range(P)]
+        recv = torch.empty(sum(out_splits), dtype=y.dtype, device=y.device)
+        self.comm.all_to_all(recv, send, out_splits, in_splits)
+        out = torch.empty((B, self.t_local, S, C), dtype=y.dtype, device=y.device)
+        ro = offsets(out_splits)
+        for q in range(P):
+            out[:, :, so[q]:so[q + 1]] = recv[ro[q]:ro[q + 1]].view(B, self.t_local, sc[q], C)
+        return out.view(B * self.t_local, S, C)
+
+    def all_reduce_sum(self, t):
+        self.comm.all_reduce_sum(t)
+
+    def gather_frames(self, x_local):
+        """(t_local, ...) per rank -> (T, ...) on every rank (final latents)."""
+        return torch.cat(self.comm.all_gather_list(x_local, self.t_counts), 0)
+
+    def take_local_rows(self, full):
+        """Rows of a (B*T, ...) replicated tensor that belong to this rank's images, in local order."""
+        idx = torch.tensor(self.local_image_ids(), device=full.device)
+        return full.index_select(0, idx)
+
+    def take_local_frames(self, full):
+        """(T, ...) -> (t_local, ...)."""
+        return full[self.t_off[self.rank]:self.t_off[self.rank + 1]]
