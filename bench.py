@@ -86,13 +86,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("VISTA_DIST_BACKEND", "nccl")  # "gloo" + VISTA_FORCE_DEVICE=0: dry run of the N>1 path on one GPU
+    if "VISTA_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["VISTA_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     shard = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
     from vista_amd import _lib, ops, synth
     from vista_amd.modules.diffusionmodules.denoiser import Denoiser
     from vista_amd.modules.diffusionmodules.sampling import EulerEDMSampler, FusedDenoiser, FusedLoop
@@ -133,7 +139,7 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:  # MAX over ranks
-        tdt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tdt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
         dt = float(tdt.item())
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
@@ -156,7 +162,7 @@ def main():
     res = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
-        "data": "synthetic",
+        "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (DRY RUN: gloo host-staged transport, ranks share one GPU -- not a result)",
         "config": {"workload": (f"{world}xMI355X" + (" frame-sharded " + "/".join(str(c) for c in shard.t_counts) if shard else "") +
                                 ": 25x576x1024 (latent 25x4x72x128), 50-step EulerEDM, VanillaCFG 2.5 (N=50 images per UNet call), "
                                 "bf16, random-init 1.65B VideoUNet, synthetic latents") if full else

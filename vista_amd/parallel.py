@@ -36,24 +36,40 @@ def offsets(counts):
 
 
 class DistComm:
+    """torch.distributed transport. With the gloo backend (CPU tests, and the single-GPU dry run of bench.py's multi-rank
+    path) device tensors are staged through host memory; with "nccl" (= RCCL) they go GPU-to-GPU over xGMI."""
+
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.host_staged = dist.get_backend(group) == "gloo"
 
     def all_to_all(self, recv, send, out_splits, in_splits):
+        if self.host_staged and recv.is_cuda:
+            r = torch.empty(recv.shape, dtype=recv.dtype)
+            self.dist.all_to_all_single(r, send.cpu(), out_splits, in_splits, group=self.group)
+            recv.copy_(r)
+            return
         self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
 
     def all_reduce_sum(self, t):
+        if self.host_staged and t.is_cuda:
+            c = t.cpu()
+            self.dist.all_reduce(c, group=self.group)
+            t.copy_(c)
+            return
         self.dist.all_reduce(t, group=self.group)
 
     def all_gather_list(self, t, counts):
         mx = max(counts)  # pad to equal sizes: uneven all_gather is not portable across backends
-        pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        pad[:t.shape[0]] = t
+        dev = t.device
+        src = t.cpu() if (self.host_staged and t.is_cuda) else t
+        pad = torch.zeros((mx,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        pad[:src.shape[0]] = src
         outs = [torch.empty_like(pad) for _ in counts]
         self.dist.all_gather(outs, pad, group=self.group)
-        return [o[:c] for o, c in zip(outs, counts)]
+        return [o[:c].to(dev) for o, c in zip(outs, counts)]
 
 
 class ThreadComm:
