@@ -6,13 +6,13 @@
 //   in 64-key tiles through a 2-stage LDS ring (K tile [64 keys][64 d], V^T tile [64 d][64 keys], 8 KiB each).
 //   The score MFMA is issued swapped, S^T = K . Q^T, so a lane owns ONE query column and 32 of the tile's keys:
 //   the row max / row sum are lane-local plus a single lane^32 exchange, and the bf16 probabilities are already
-//   in MFMA B-operand position for O^T = V^T . P^T -- the PV contraction simply enumerates the keys in the order
-//   the accumulator holds them (k-slot (half h, i) <-> key 16J + 8*(i>>2) + 4h + (i&3)) and the V^T fragment is
-//   read from LDS in that same order (two ds_read_b64 per fragment). No cross-lane permutes, no P round trip.
-//   V^T ([img][head][64][S]) is produced directly by the value projection GEMM (EPI_TRANS), so both LDS tiles are
-//   filled with plain coalesced 16-B row chunks.
-//   LDS swizzles: K rows are 128 B, 16-B chunk ^= (row>>1)&7 (ds_read_b128 conflict-free); V^T rows are 128 B,
-//   8-B unit ^= (d>>1)&15 (ds_read_b64 conflict-free; an odd key swaps the two halves of the 16-B write).
+//   in MFMA B-operand position for O^T = V^T . P^T. The K tile's rows are stored PERMUTED (row bits [g1 g0 h e1 e0] hold
+//   key [g1 h g0 e1 e0]) so that the 8 accumulator registers feeding one PV k-step hold 8 contiguous keys: the matching
+//   V^T fragment is a single aligned ds_read_b128. No cross-lane permutes, no P round trip through LDS.
+//   V^T ([img][head][64][S]) is produced directly by the value projection GEMM (EPI_TRANS). Both tiles are filled by
+//   LDS-DMA (global_load_lds_dwordx4; the row permutation and the bank swizzle live in the per-lane SOURCE address,
+//   keys past the sequence end read a zero word), 2-stage ring, one barrier per 64-key tile.
+//   LDS swizzle (both tiles, 128-B rows): 16-B chunk ^= (row>>1)&7 -> ds_read_b128 conflict-free.
 //
 // vk_attn_temporal_bf16 -- per-pixel attention over the T (<=32) frames (VideoTransformerBlock.attn1;
 //   vwm/modules/video_attention.py:116-127, attention.py:384-399): one wave per (batch, pixel, head); Q/K
@@ -33,15 +33,26 @@ __device__ __forceinline__ bf16x8_t make_frag(uint2 a, uint2 b) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
+__device__ uint4 g_attn_zero16;  // zero source for keys past the end of the sequence (LDS-DMA cannot predicate its write)
+
+// actual key (within a 32-key subtile) held by K-tile LDS row rho: bits [g1 g0 h e1 e0] -> [g1 h g0 e1 e0].
+// With this row permutation the accumulator registers 8*(J&1)..+7 of lane-half h hold the 8 CONTIGUOUS keys 16J + 8h + 0..7,
+// so the matching V^T fragment is one aligned 16-byte LDS read.
+__device__ __forceinline__ int key_of_row(int rho32) {
+    const int g = rho32 >> 3, h = (rho32 >> 2) & 1, e = rho32 & 3;
+    return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + e;
+}
+
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
                                                                int n_img, int heads, int S, int ldq, int ldk, int ldo,
                                                                float scale_log2) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // per stage: K tile 8 KiB | V^T tile 8 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     const int nqb = (S + 127) >> 7;
     const int logical = xcd_remap(blockIdx.x, nqb * n_img * heads);
@@ -58,50 +69,42 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qptr + 16 * ks);
 
-    // ---- K / V^T staging: thread owns 16-B chunk lc of rows lr, lr+32 ----
-    const int lc = tid & 7, lr = tid >> 3;
-    const uint16_t* kbase = k + (size_t)img * S * ldk + head * 64 + lc * 8;
-    const uint16_t* vbase = vt + ((size_t)(img * heads + head) * 64) * S + lc * 8;
-    const int ksw = (lr >> 1) & 7;          // K row swizzle (invariant under +32)
-    const int vg = (lr >> 1) & 15;          // V^T unit swizzle of row d=lr   (row d+32 has the same (d>>1)&15)
-    const int k_st = lr * 128 + ((lc ^ ksw) << 4);
-    const int v_st = lr * 128 + ((lc ^ (vg >> 1)) << 4);
-
-    uint4 rk[2], rv[2];
-    auto load_tile = [&](int t) {
-        const int key0 = t * 64;
+    // ---- K / V^T staging by LDS-DMA: wave w fills the 8-row groups w and w+4 of both tiles; lane -> row (lane>>3) of the
+    //      group, physical 16-B slot (lane&7); the swizzle (slot = chunk ^ ((row>>1)&7)) is applied on the SOURCE chunk ----
+    const int dj = lane >> 3, dslot = lane & 7;
+    int k_key[2], d_row[2], src_chunk[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = key0 + lr + 32 * i;
-            rk[i] = (key < S) ? *(const uint4*)(kbase + (size_t)key * ldk) : make_uint4(0, 0, 0, 0);
-            const int kk = key0 + lc * 8;
-            rv[i] = (kk < S) ? *(const uint4*)(vbase + (size_t)(lr + 32 * i) * S + key0) : make_uint4(0, 0, 0, 0);  // vbase already has +lc*8
-        }
-    };
-    auto store_tile = [&](int stage) {
-        char* sK = smem + stage * 16384;
+    for (int i = 0; i < 2; ++i) {
+        const int rho = 8 * (wave + 4 * i) + dj;                 // LDS row of both tiles handled by this lane
+        src_chunk[i] = dslot ^ ((rho >> 1) & 7);
+        k_key[i] = (rho & 32) + key_of_row(rho & 31);            // key (within the 64-key tile) stored in K row rho
+        d_row[i] = rho;                                           // V^T row = head-dim index d
+    }
+    const uint16_t* kbase = k + (size_t)img * S * ldk + head * 64;
+    const uint16_t* vbase = vt + ((size_t)(img * heads + head) * 64) * S;
+
+    auto dma_tile = [&](int t, int stage) {
+        typedef const __attribute__((address_space(1))) void* gptr_t;
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const int key0 = t * 64;
+        char* sK = smem + stage * 16384 + wave_u * 1024;
         char* sV = sK + 8192;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            *(uint4*)(sK + k_st + i * 32 * 128) = rk[i];
-            uint4 v = rv[i];
-            if (vg & 1) v = make_uint4(v.z, v.w, v.x, v.y);
-            *(uint4*)(sV + v_st + i * 32 * 128) = v;
+            const int key = key0 + k_key[i];
+            const uint16_t* ksrc = (key < S) ? kbase + (size_t)key * ldk + src_chunk[i] * 8 : (const uint16_t*)&g_attn_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)ksrc, (lptr_t)(sK + i * 4096), 16, 0, 0);
+            const int kk = key0 + src_chunk[i] * 8;               // first key of this 8-key chunk (S % 8 == 0)
+            const uint16_t* vsrc = (kk < S) ? vbase + (size_t)d_row[i] * S + kk : (const uint16_t*)&g_attn_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)vsrc, (lptr_t)(sV + i * 4096), 16, 0, 0);
         }
     };
 
-    // fragment read offsets
+    // fragment read offsets: row l31 (+32 per subtile), logical chunk 2*ks + lh, same swizzle for K and V^T tiles
     const int fsw = (l31 >> 1) & 7;
-    int kfrag_off[4];
+    int frag_off[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kfrag_off[ks] = l31 * 128 + (((ks * 2 + lh) ^ fsw) << 4);
-    const int fvg = (l31 >> 1) & 15;
-    int vfrag_off[4][2];
-#pragma unroll
-    for (int J = 0; J < 4; ++J) {
-        vfrag_off[J][0] = l31 * 128 + (((4 * J + lh) ^ fvg) << 3);
-        vfrag_off[J][1] = l31 * 128 + (((4 * J + 2 + lh) ^ fvg) << 3);
-    }
+    for (int ks = 0; ks < 4; ++ks) frag_off[ks] = l31 * 128 + (((ks * 2 + lh) ^ fsw) << 4);
 
     f32x16_t oacc[2];
 #pragma unroll
@@ -111,13 +114,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
     float m_run = NEG_BIG, l_run = 0.f;
 
     const int nt = (S + 63) >> 6;
-    load_tile(0);
-    store_tile(0);
+    dma_tile(0, 0);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const int stage = t & 1;
-        if (t + 1 < nt) load_tile(t + 1);
+        if (t + 1 < nt) dma_tile(t + 1, stage ^ 1);
         const char* sK = smem + stage * 16384;
         const char* sV = sK + 8192;
 
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
             for (int r = 0; r < 16; ++r) sacc[c][r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sK + c * 32 * 128 + kfrag_off[ks]);
+                const bf16x8_t kf = *(const bf16x8_t*)(sK + c * 32 * 128 + frag_off[ks]);
                 sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[c], 0, 0, 0);
             }
         }
@@ -138,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
             for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = t * 64 + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    // accumulator row rho32 = (r&3) + 8*(r>>2) + 4*lh holds key key_of_row(rho32) of subtile c
+                    const int key = t * 64 + c * 32 + key_of_row((r & 3) + 8 * (r >> 2) + 4 * lh);
                     if (key >= S) sacc[c][r] = NEG_BIG;
                 }
         }
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
             }
         l_run += psum;
 
-        // ---- P^T fragments: k-step J holds accumulator regs 8*(J&1)..+7 of key subtile J>>1 ----
+        // ---- P^T fragments: k-step J = accumulator regs 8*(J&1)..+7 of key subtile J>>1 = keys 16J + 8*lh + 0..7 ----
         bf16x8_t pf[4];
 #pragma unroll
         for (int J = 0; J < 4; ++J) {
@@ -185,19 +188,16 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
             pf[J] = __builtin_bit_cast(bf16x8_t, v);
         }
 
-        // ---- O^T[d][q] += V^T . P^T ----
+        // ---- O^T[d][q] += V^T . P^T : V^T fragment (row d = 32*dd + l31, keys 16J + 8*lh ..+7) is one ds_read_b128 ----
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #pragma unroll
             for (int J = 0; J < 4; ++J) {
-                const uint2 va = *(const uint2*)(sV + d * 32 * 128 + vfrag_off[J][0]);
-                const uint2 vb = *(const uint2*)(sV + d * 32 * 128 + vfrag_off[J][1]);
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(make_frag(va, vb), pf[J], oacc[d], 0, 0, 0);
+                const bf16x8_t vf = *(const bf16x8_t*)(sV + d * 32 * 128 + frag_off[J]);
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[J], oacc[d], 0, 0, 0);
             }
         }
-
-        if (t + 1 < nt) store_tile(stage ^ 1);
-        __syncthreads();
+        __syncthreads();  // retires the DMA of tile t+1 (vmcnt(0)) and frees this stage
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

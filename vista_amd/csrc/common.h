@@ -43,9 +43,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-// exact (erf) GELU, as F.gelu default in the reference (vwm/modules/attention.py:92)
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+// erf-form GELU (F.gelu default, reference vwm/modules/attention.py:92): x * Phi(x), Phi evaluated branch-free through
+// erfc(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z) (Abramowitz-Stegun 7.1.26, |abs err| <= 1.5e-7 -- four orders
+// below bf16 resolution); the negative side uses 0.5*erfc directly, so there is no 1 - erf cancellation.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(t, 1.061405429f, -1.453152027f);
+    poly = fmaf(t, poly, 1.421413741f);
+    poly = fmaf(t, poly, -0.284496736f);
+    poly = fmaf(t, poly, 0.254829592f);
+    poly *= t;
+    const float q = 0.5f * poly * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);  // 0.5 * erfc(|x|/sqrt2) = Phi(-|x|)
+    const float cdf = (x >= 0.f) ? 1.f - q : q;
+    return x * cdf;
+}
 
 // XCD-aware, bijective block remap (8 XCDs, block b is observed on XCD b%8): gives each XCD a
 // contiguous range of logical tile ids so neighbouring tiles share that XCD's private L2.
