@@ -1,0 +1,41 @@
+"""Run ONE hot kernel at a BASELINE shape a few times (for rocprofv3 --pmc passes).
+usage: python tools/one_kernel.py {attn|conv|geglu|ffout|linear} [level 0|1|2]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vista_amd import ops  # noqa: E402
+
+BF16 = torch.bfloat16
+kind = sys.argv[1]
+lvl = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+C, H, W, heads = [(320, 72, 128, 5), (640, 36, 64, 10), (1280, 18, 32, 20)][lvl]
+N = 50
+S = H * W
+M = N * S
+x = torch.randn(M, C, device="cuda").to(BF16)
+if kind == "attn":
+    pqk = ops.pack_linear_cat([torch.randn(C, C) * C ** -0.5, torch.randn(C, C) * C ** -0.5])
+    pv = ops.pack_linear(torch.randn(C, C) * C ** -0.5, None)
+    qk = ops.linear(x, pqk)
+    vt = ops.linear_vt(x, pv, S)
+    fn = lambda: ops.attn_spatial(qk[:, :C], qk[:, C:], vt, N, heads, S)  # noqa: E731
+elif kind == "conv":
+    pc = ops.pack_conv3x3(torch.randn(C, C, 3, 3) * (9 * C) ** -0.5, torch.randn(C))
+    x3 = x.view(N, S, C)
+    fn = lambda: ops.conv3x3(x3, pc, N, H, W)  # noqa: E731
+elif kind == "geglu":
+    pg = ops.pack_geglu(torch.randn(8 * C, C) * C ** -0.5, torch.randn(8 * C))
+    fn = lambda: ops.linear(x, pg)  # noqa: E731
+elif kind == "ffout":
+    h = torch.randn(M, 4 * C, device="cuda").to(BF16)
+    po = ops.pack_linear(torch.randn(C, 4 * C) * (4 * C) ** -0.5, torch.randn(C))
+    fn = lambda: ops.linear(h, po, res1=x)  # noqa: E731
+else:
+    pw = ops.pack_linear(torch.randn(C, C) * C ** -0.5, torch.randn(C))
+    fn = lambda: ops.linear(x, pw)  # noqa: E731
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()

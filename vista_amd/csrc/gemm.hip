@@ -227,9 +227,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
         dma_tile(0, 0);
         __syncthreads();
+        const bool skip_dma = (p.tile_cfg & 16) != 0;  // timing experiment only (results are wrong): no DMA after tile 0
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
-            if (kt + 1 < nk) dma_tile(kt + 1, stage ^ 1);
+            if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
             compute(stage);
             __syncthreads();
         }
@@ -391,7 +392,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 15) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 31) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;

@@ -135,6 +135,7 @@ class FrameShard:
         self.t_counts = split_counts(T, self.P)
         self.t_off = offsets(self.t_counts)
         self.t_local = self.t_counts[self.rank]
+        self._plans = {}
 
     # global image ids (b*T + t) of this rank's frames, in local (b, t_local) order
     def local_image_ids(self):
@@ -144,45 +145,67 @@ class FrameShard:
     def pixel_counts(self, S):
         return split_counts(S, self.P)
 
-    def to_pixels(self, x):
-        """(B*t_local, S, C) frame-sharded -> (B*T, S_r, C) pixel-sharded (frames in global order)."""
-        B, P, r = self.B, self.P, self.rank
-        n, S, C = x.shape
-        t_l = self.t_local
-        assert n == B * t_l
+    # ---- exchanges. Packing / unpacking is one row gather each (cached int64 index tensors), so an exchange is
+    #      gather -> all-to-all -> gather regardless of the number of ranks.
+    def _plan(self, S, device):
+        key = (S, str(device))
+        if key in self._plans:
+            return self._plans[key]
+        B, P, r, T, t_l = self.B, self.P, self.rank, self.T, self.t_local
         sc = self.pixel_counts(S)
         so = offsets(sc)
-        x4 = x.view(B, t_l, S, C)
-        send = torch.cat([x4[:, :, so[q]:so[q + 1]].reshape(-1) for q in range(P)])
-        in_splits = [B * t_l * sc[q] * C for q in range(P)]
-        out_splits = [B * self.t_counts[q] * sc[r] * C for q in range(P)]
-        recv = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
-        self.comm.all_to_all(recv, send, out_splits, in_splits)
-        out = torch.empty((B, self.T, sc[r], C), dtype=x.dtype, device=x.device)
-        ro = offsets(out_splits)
+        s_r = sc[r]
+        ar = torch.arange
+        # frames -> pixels: send buffer = for q: rows (b, t_local, s in slice q) of x viewed (B*t_l*S, C)
+        pack_fp = torch.cat([((ar(B)[:, None, None] * t_l + ar(t_l)[None, :, None]) * S + (so[q] + ar(sc[q]))[None, None, :]).reshape(-1)
+                             for q in range(P)])
+        # received = for q: (B, t_q, s_r); output rows (b, t_global, s) of (B*T*s_r, C) gather from the received buffer
+        ro = offsets([B * self.t_counts[q] * s_r for q in range(P)])
+        unpack_fp = torch.empty(B, T, s_r, dtype=torch.int64)
         for q in range(P):
-            out[:, self.t_off[q]:self.t_off[q + 1]] = recv[ro[q]:ro[q + 1]].view(B, self.t_counts[q], sc[r], C)
-        return out.view(B * self.T, sc[r], C)
+            tq = self.t_counts[q]
+            unpack_fp[:, self.t_off[q]:self.t_off[q + 1]] = ro[q] + ((ar(B)[:, None, None] * tq + ar(tq)[None, :, None]) * s_r + ar(s_r)[None, None, :])
+        # pixels -> frames: send buffer = for q: rows (b, t in q's frames, s) of y viewed (B*T*s_r, C)
+        pack_pf = torch.cat([((ar(B)[:, None, None] * T + (self.t_off[q] + ar(self.t_counts[q]))[None, :, None]) * s_r + ar(s_r)[None, None, :]).reshape(-1)
+                             for q in range(P)])
+        ro2 = offsets([B * t_l * sc[q] for q in range(P)])
+        unpack_pf = torch.empty(B, t_l, S, dtype=torch.int64)
+        for q in range(P):
+            unpack_pf[:, :, so[q]:so[q + 1]] = ro2[q] + ((ar(B)[:, None, None] * t_l + ar(t_l)[None, :, None]) * sc[q] + ar(sc[q])[None, None, :])
+        plan = {"sc": sc, "s_r": s_r,
+                "pack_fp": pack_fp.to(device), "unpack_fp": unpack_fp.reshape(-1).to(device),
+                "pack_pf": pack_pf.to(device), "unpack_pf": unpack_pf.reshape(-1).to(device)}
+        self._plans[key] = plan
+        return plan
+
+    def to_pixels(self, x):
+        """(B*t_local, S, C) frame-sharded -> (B*T, S_r, C) pixel-sharded (frames in global order)."""
+        B, P = self.B, self.P
+        n, S, C = x.shape
+        assert n == B * self.t_local
+        pl = self._plan(S, x.device)
+        sc, s_r = pl["sc"], pl["s_r"]
+        send = x.reshape(n * S, C).index_select(0, pl["pack_fp"])
+        in_splits = [B * self.t_local * sc[q] * C for q in range(P)]
+        out_splits = [B * self.t_counts[q] * s_r * C for q in range(P)]
+        recv = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
+        self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
+        return recv.view(-1, C).index_select(0, pl["unpack_fp"]).view(B * self.T, s_r, C)
 
     def to_frames(self, y, S):
         """(B*T, S_r, C) pixel-sharded -> (B*t_local, S, C) frame-sharded."""
-        B, P, r = self.B, self.P, self.rank
+        B, P = self.B, self.P
         n, s_r, C = y.shape
         assert n == B * self.T
-        sc = self.pixel_counts(S)
-        so = offsets(sc)
-        assert s_r == sc[r]
-        y4 = y.view(B, self.T, s_r, C)
-        send = torch.cat([y4[:, self.t_off[q]:self.t_off[q + 1]].reshape(-1) for q in range(P)])
+        pl = self._plan(S, y.device)
+        sc = pl["sc"]
+        assert s_r == pl["s_r"]
+        send = y.reshape(n * s_r, C).index_select(0, pl["pack_pf"])
         in_splits = [B * self.t_counts[q] * s_r * C for q in range(P)]
         out_splits = [B * self.t_local * sc[q] * C for q in range(P)]
         recv = torch.empty(sum(out_splits), dtype=y.dtype, device=y.device)
-        self.comm.all_to_all(recv, send, out_splits, in_splits)
-        out = torch.empty((B, self.t_local, S, C), dtype=y.dtype, device=y.device)
-        ro = offsets(out_splits)
-        for q in range(P):
-            out[:, :, so[q]:so[q + 1]] = recv[ro[q]:ro[q + 1]].view(B, self.t_local, sc[q], C)
-        return out.view(B * self.t_local, S, C)
+        self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
+        return recv.view(-1, C).index_select(0, pl["unpack_pf"]).view(B * self.t_local, S, C)
 
     def all_reduce_sum(self, t):
         self.comm.all_reduce_sum(t)
