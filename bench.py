@@ -146,8 +146,8 @@ def main():
     assert torch.isfinite(loop.xw).all(), "non-finite latents"
     ms_per_step = dt * 1e3 / args.steps
     value = args.steps / dt
-
     full = (T, H, W, args.model_channels) == (25, 72, 128, 320)
+
     l0 = [(e0.elapsed_time(e1), nbh) for (S, nbh, e0, e1) in prof if S == H * W]
     roofline = None
     if l0:
@@ -156,8 +156,12 @@ def main():
         avg_ms = sum(l0) / len(l0)
         flop = 4.0 * nbh * float(H * W) ** 2 * 64
         ach = flop / (avg_ms * 1e-3) / 1e12
+        traffic = None  # HBM bytes per launch from the separate PMC passes (profiles/r01_attn_traffic.json), full config only
+        tp = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+        if full and world == 1 and os.path.exists(tp):
+            traffic = json.load(open(tp))["traffic_bytes_per_launch"]
         roofline = {"kernel": "attn_spatial_kernel (level-0 spatial self-attention)", "bound": "mfma", "achieved": ach,
-                    "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": None,
+                    "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": traffic,
                     "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop}
     res = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -117,6 +117,14 @@ def main():
         res[name] = out.clone()
         res[name + "_noise_after"] = noise.clone()  # the reference scales the caller's tensor in place (sampling.py:36)
         print(f"sampler {name}: rms {out.pow(2).mean().sqrt():.4f}")
+    # rollout-style window (BASELINE config 4; sample_utils.py:338-365): the first THREE frames are conditioning frames carried
+    # over from the previous window, per-frame triangle guidance, trajectory action embedding in the context
+    w3 = synth.window_inputs(T=T, H=H, W=W, seed=22, n_cond=3, trajectory=[1.0, 0.2, 2.0, 0.5, 3.0, 0.9, 4.0, 1.4])
+    sampler = c["EulerEDMSampler"](num_steps=3, discretization_config=disc_cfg, guider_config=guiders["triangle"], s_churn=0.0, s_tmin=0.0,
+                                   s_tmax=999.0, s_noise=1.0, verbose=False, device="cpu")
+    res["rollout3"] = sampler(denoiser, w3["noise"].clone(), cond={k: v.clone() for k, v in w3["c"].items()},
+                              uc={k: v.clone() for k, v in w3["uc"].items()}, cond_frame=w3["cond_frame"], cond_mask=w3["cond_mask"]).clone()
+    print(f"sampler rollout3: rms {res['rollout3'].pow(2).mean().sqrt():.4f}")
     # one plain Denoiser.forward for the boundary test
     sig = torch.full((2 * T,), 5.0)
     x2, s2, c2, m2 = g.VanillaCFG(2.5).prepare_inputs(w["noise"] * 5.0, sig[:T], w["c"], w["cond_mask"], w["uc"])

@@ -109,6 +109,13 @@ def test_sampler_and_denoiser_vs_reference_golden():
             assert torch.allclose(noise.cpu(), g[name + "_noise_after"], rtol=1e-5, atol=1e-5)
             # cond frames are replaced exactly at the end (sampling.py:122)
             assert torch.equal(out[0], w["cond_frame"][0])
+    # rollout-style window (BASELINE config 4): 3 carried-over cond frames, triangle guidance, trajectory action embedding
+    w3 = synth.window_inputs(T=T, H=H, W=W, seed=22, n_cond=3, trajectory=[1.0, 0.2, 2.0, 0.5, 3.0, 0.9, 4.0, 1.4])
+    out = _sampler(cfgs["triangle"])(fused, w3["noise"].clone().cuda(), cond=cuda(w3["c"]), uc=cuda(w3["uc"]),
+                                     cond_frame=w3["cond_frame"].cuda(), cond_mask=w3["cond_mask"].cuda()).cpu()
+    r = rel_l2(out, g["rollout3"])
+    print(f"[parity] sampler rollout3 (3 cond frames, triangle): rel-L2 {r:.4e}")
+    assert r <= 4e-2 and torch.equal(out[:3], w3["cond_frame"][:3])
     # plain Denoiser.forward boundary
     sig = torch.full((T,), 5.0)
     x2, s2, c2, m2 = guiders.VanillaCFG(2.5).prepare_inputs((w["noise"] * 5.0).cuda(), sig.cuda(), cuda(w["c"]), w["cond_mask"].cuda(),
@@ -135,6 +142,24 @@ def test_unet_properties_batch_and_determinism():
     assert torch.equal(oab[:2 * T], oa) and torch.equal(oab[2 * T:], ob)
     oa2 = net(xa[0], timesteps=xa[1], context=xa[2], y=xa[3], cond_mask=xa[4], num_frames=T)
     assert torch.equal(oa2, oa)
+
+
+def test_unet_full_latent_size_tiny_width_vs_oracle():
+    """BASELINE latent size (25 frames, 72x128 -> token counts 9216/2304/576/144 incl. ragged attention tiles) with the
+    64-channel network, against the CPU oracle computed here (the oracle is pinned to the reference by tests/test_oracle_cpu.py)."""
+    from oracle import vista_oracle as O
+    from oracle.make_golden import unet_inputs
+    from vista_amd import synth
+    net, shapes = tiny_unet()
+    sd = synth.seeded_state_dict(shapes, 0)
+    T, H, W = 25, 72, 128
+    x8, ts, ctx, y, mask = unet_inputs(T, H, W, seed=77, sigma=12.0)
+    with torch.no_grad():
+        ref = O.unet_forward(sd, x8, ts, ctx, y, mask, T)
+    out = net(x8.cuda(), timesteps=ts.cuda(), context=ctx.cuda(), y=y.cuda(), cond_mask=mask.cuda(), num_frames=T).cpu()
+    r, mx = rel_l2(out, ref), ((out - ref).abs().max() / ref.abs().max()).item()
+    print(f"[parity] tiny-width UNet at the full 25x72x128 latent vs oracle: rel-L2 {r:.4e} max-rel {mx:.4e}")
+    assert torch.isfinite(out).all() and r <= 2.5e-2 and mx <= 8e-2
 
 
 def test_product_path_refuses_cpu():

@@ -71,6 +71,11 @@ def test_oracle_sampler_matches_reference_golden():
                                     ("triangle", O.triangle_guider_scale(T), "cfg"), ("identity", None, "identity")):
             out = O.euler_edm_sample(denoise, w["noise"], w["c"], w["uc"], w["cond_frame"], w["cond_mask"], 3, scale=scale, guider=guider)
             assert _rel(out, g[name]) < 5e-4, name
+        # rollout-style window: 3 carried-over cond frames, triangle guidance, another trajectory (BASELINE config 4)
+        w3 = synth.window_inputs(T=T, H=H, W=W, seed=22, n_cond=3, trajectory=[1.0, 0.2, 2.0, 0.5, 3.0, 0.9, 4.0, 1.4])
+        out = O.euler_edm_sample(denoise, w3["noise"], w3["c"], w3["uc"], w3["cond_frame"], w3["cond_mask"], 3, scale=O.triangle_guider_scale(T))
+        assert _rel(out, g["rollout3"]) < 5e-4
+        assert torch.equal(out[:3], w3["cond_frame"][:3])
         sig = torch.full((T,), 5.0)
         x2, s2, c2, m2 = O.guider_prepare_inputs(w["noise"] * 5.0, sig, w["c"], w["cond_mask"], w["uc"])
         assert _rel(denoise(x2, s2, c2, m2), g["denoiser_out"]) < 2e-4
