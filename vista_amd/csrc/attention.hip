@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 
         // ---- S^T[key][q] = K . Q^T ----
         f32x16_t sacc[2];
+        __builtin_amdgcn_s_setprio(1);  // favour the wave that is in a matrix phase over co-resident waves issuing loads / softmax VALU
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                 sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[c], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (t == nt - 1 && (S & 63)) {  // mask keys past the end of the sequence (last tile only)
 #pragma unroll
             for (int c = 0; c < 2; ++c)
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
         }
 
         // ---- O^T[d][q] += V^T . P^T : V^T fragment (row d = 32*dd + l31, keys 16J + 8*lh ..+7) is one ds_read_b128 ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #pragma unroll
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
                 oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[J], oacc[d], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();  // retires the DMA of tile t+1 (vmcnt(0)) and frees this stage
     }
 

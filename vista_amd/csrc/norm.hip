@@ -34,7 +34,20 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
         const uint16_t* p = x + ((size_t)img * S) * C + chunk * 8;
-        for (int t = tok0 + r; t < tok1; t += R) {
+        int t = tok0 + r;
+        for (; t + 3 * R < tok1; t += 4 * R) {  // 4 independent 16-B loads in flight per thread
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(p + (size_t)(t + u * R) * C);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] = fmaf(f[e], f[e], sq[e]); }
+            }
+        }
+        for (; t < tok1; t += R) {
             const uint4 v = *(const uint4*)(p + (size_t)t * C);
             float f[8];
             unpack8(v, f);
@@ -100,14 +113,31 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
         b[e] = beta[c] - mean * a[e];
     }
     const size_t base = ((size_t)img * S) * C + chunk * 8;
-    for (int t = tok0 + r; t < tok1; t += R) {
+    int t = tok0 + r;
+    for (; t + 3 * R < tok1; t += 4 * R) {  // 4 independent 16-B loads in flight per thread
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(x + base + (size_t)(t + u * R) * C);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float f[8];
+            unpack8(v[u], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float w = fmaf(f[e], a[e], b[e]);
+                f[e] = do_silu ? silu_f(w) : w;
+            }
+            *(uint4*)(y + base + (size_t)(t + u * R) * C) = pack8(f);
+        }
+    }
+    for (; t < tok1; t += R) {
         const uint4 v = *(const uint4*)(x + base + (size_t)t * C);
         float f[8];
         unpack8(v, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float u = fmaf(f[e], a[e], b[e]);
-            f[e] = do_silu ? silu_f(u) : u;
+            const float w = fmaf(f[e], a[e], b[e]);
+            f[e] = do_silu ? silu_f(w) : w;
         }
         *(uint4*)(y + base + (size_t)t * C) = pack8(f);
     }
