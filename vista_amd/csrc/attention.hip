@@ -2,7 +2,7 @@
 //
 // vk_attn_spatial_bf16 -- flash-style spatial self-attention (BasicTransformerBlock.attn1;
 //   vwm/modules/attention.py:370-407,514-518): per (image, head), N = H*W tokens, d = 64, no mask.
-//   Work decomposition: one workgroup = 128 query rows (4 waves x 32 rows) of one (image, head); KV is streamed
+//   Work decomposition: one workgroup = 256 (S >= 2048) or 128 query rows (8 / 4 waves x 32 rows) of one (image, head); KV is streamed
 //   in 64-key tiles through a 2-stage LDS ring (K tile [64 keys][64 d], V^T tile [64 d][64 keys], 8 KiB each).
 //   The score MFMA is issued swapped, S^T = K . Q^T, so a lane owns ONE query column and 32 of the tile's keys:
 //   the row max / row sum are lane-local plus a single lane^32 exchange, and the bf16 probabilities are already
@@ -43,10 +43,13 @@ __device__ __forceinline__ int key_of_row(int rho32) {
     return 16 * (g >> 1) + 8 * h + 4 * (g & 1) + e;
 }
 
-__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
-                                                               const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
-                                                               int n_img, int heads, int S, int ldq, int ldk, int ldo,
-                                                               float scale_log2) {
+template <int NW>  // waves per workgroup: NW*32 query rows share each 64-key K / V^T tile
+__global__ __launch_bounds__(NW * 64, 2) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                                  const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
+                                                                  int n_img, int heads, int S, int ldq, int ldk, int ldo,
+                                                                  float scale_log2) {
+    constexpr int QB = NW * 32;   // query rows per workgroup
+    constexpr int GPW = 8 / NW;   // 8-row DMA groups of each tile handled per wave
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // per stage: K tile 8 KiB | V^T tile 8 KiB
 
     const int tid = threadIdx.x;
@@ -54,13 +57,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
     const int l31 = lane & 31, lh = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-    const int nqb = (S + 127) >> 7;
+    const int nqb = (S + QB - 1) / QB;
     const int logical = xcd_remap(blockIdx.x, nqb * n_img * heads);
     const int bh = logical / nqb, qb = logical - bh * nqb;
     const int img = bh / heads, head = bh - img * heads;
 
     // ---- Q fragments (B operand: column = query row, 8 consecutive d at 16*ks + 8*lh) ----
-    const int q0 = qb * 128 + wave * 32;
+    const int q0 = qb * QB + wave * 32;
     int qrow = q0 + l31;
     const bool q_ok = qrow < S;
     if (!q_ok) qrow = S - 1;
@@ -69,13 +72,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qptr + 16 * ks);
 
-    // ---- K / V^T staging by LDS-DMA: wave w fills the 8-row groups w and w+4 of both tiles; lane -> row (lane>>3) of the
+    // ---- K / V^T staging by LDS-DMA: wave w fills the 8-row groups w, w+NW, .. of both tiles; lane -> row (lane>>3) of the
     //      group, physical 16-B slot (lane&7); the swizzle (slot = chunk ^ ((row>>1)&7)) is applied on the SOURCE chunk ----
     const int dj = lane >> 3, dslot = lane & 7;
-    int k_key[2], d_row[2], src_chunk[2];
+    int k_key[GPW], d_row[GPW], src_chunk[GPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rho = 8 * (wave + 4 * i) + dj;                 // LDS row of both tiles handled by this lane
+    for (int i = 0; i < GPW; ++i) {
+        const int rho = 8 * (wave + NW * i) + dj;                // LDS row of both tiles handled by this lane
         src_chunk[i] = dslot ^ ((rho >> 1) & 7);
         k_key[i] = (rho & 32) + key_of_row(rho & 31);            // key (within the 64-key tile) stored in K row rho
         d_row[i] = rho;                                           // V^T row = head-dim index d
@@ -90,13 +93,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const uint16_t* __
         char* sK = smem + stage * 16384 + wave_u * 1024;
         char* sV = sK + 8192;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < GPW; ++i) {
             const int key = key0 + k_key[i];
             const uint16_t* ksrc = (key < S) ? kbase + (size_t)key * ldk + src_chunk[i] * 8 : (const uint16_t*)&g_attn_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)ksrc, (lptr_t)(sK + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)ksrc, (lptr_t)(sK + i * NW * 1024), 16, 0, 0);
             const int kk = key0 + src_chunk[i] * 8;               // first key of this 8-key chunk (S % 8 == 0)
             const uint16_t* vsrc = (kk < S) ? vbase + (size_t)d_row[i] * S + kk : (const uint16_t*)&g_attn_zero16;
-            __builtin_amdgcn_global_load_lds((gptr_t)vsrc, (lptr_t)(sV + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)vsrc, (lptr_t)(sV + i * NW * 1024), 16, 0, 0);
         }
     };
 
@@ -345,11 +348,19 @@ extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt
                                     int32_t S, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream_) {
     if (!q || !k || !vt || !o || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;
     if ((S % 8) != 0 || (ldq % 8) != 0 || (ldk % 8) != 0 || (ldo % 4) != 0) return VK_EINVAL;
-    const int nqb = (S + 127) / 128;
+    // long sequences: 256 query rows (8 waves) per workgroup halve the K/V^T stream per FLOP; short ones keep 128 rows so the
+    // ragged last q-block wastes less (S = 144, 576 at the deep levels)
+    const bool big = S >= 2048;
+    const int qb_rows = big ? 256 : 128;
+    const int nqb = (S + qb_rows - 1) / qb_rows;
     const long long nblk = (long long)nqb * n_img * heads;
     if (nblk > 0x7fffffffLL) return VK_EINVAL;
-    hipLaunchKernelGGL(attn_spatial_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)q,
-                       (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E);
+    if (big)
+        hipLaunchKernelGGL(attn_spatial_kernel<8>, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream_, (const uint16_t*)q,
+                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E);
+    else
+        hipLaunchKernelGGL(attn_spatial_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)q,
+                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }

@@ -364,20 +364,25 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
     return VK_OK;
 }
 
-// Tile-shape choice (host side, per problem): small problems keep the 128x128 tile; otherwise 256x256 unless rounding N up
-// to 256 wastes more than ~10% of the MFMA work, in which case 256x128.
+// Tile-shape choice (host side, per problem). Preference order: 256x320 (N a multiple of 320, not GEGLU), 256x256 (unless
+// rounding N up to 256 wastes > 10% of the MFMA work), 256x128, 128x128 -- but a variant is only taken if its grid covers the
+// chip (>= 256 workgroups, one per CU; the 128x128 variant runs two per CU). Small-M problems (deep UNet levels, and every
+// level of a frame-sharded multi-GPU run) therefore fall back to smaller tiles instead of leaving CUs idle.
 template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
     const int force = d->tile_cfg & 7;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (tests / tuning)
     int cfg = force;
     if (cfg == 4 && EPI == EPI_GEGLU) cfg = 3;  // the GEGLU packing needs 64-column wave tiles
     if (cfg == 0) {
-        if ((long long)d->M * d->N < (1LL << 21) || d->M < 1024) cfg = 1;
-        else if (EPI != EPI_GEGLU && d->N % 320 == 0) cfg = 4;
-        else {
-            const int n256 = (d->N + 255) / 256 * 256;
-            cfg = (n256 * 10 <= d->N * 11) ? 3 : 2;
-        }
+        auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
+        const int n256 = (d->N + 255) / 256 * 256;
+        const bool ok320 = (EPI != EPI_GEGLU) && (d->N % 320 == 0);
+        const bool ok256 = n256 * 10 <= d->N * 11;
+        const long long need = 256;
+        if (ok320 && wgs(256, 320) >= need) cfg = 4;
+        else if (ok256 && wgs(256, 256) >= need) cfg = 3;
+        else if (wgs(256, 128) >= need) cfg = 2;
+        else cfg = 1;
     }
     if constexpr (EPI != EPI_GEGLU) {
         if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 5>(d, stream);
