@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--latent-w", type=int, default=128)
     ap.add_argument("--model-channels", type=int, default=320)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=["hybrid", "frames"], default="hybrid")
     ap.add_argument("--cpu-sample", type=str, default="16x32")
     args = ap.parse_args()
 
@@ -107,8 +108,13 @@ def main():
 
     T, H, W = args.frames, args.latent_h, args.latent_w
     if world > 1:
-        from vista_amd.parallel import DistComm, FrameShard
-        shard = FrameShard(T, DistComm(), B=2)  # frames 25 -> 4/3/3/3/3/3/3/3 at 8 GPUs; pixel-sharded temporal halves
+        from vista_amd.parallel import DistComm, make_shard
+
+        def make_group(ranks):  # collective: every rank creates every group, members get a communicator
+            g = dist.new_group(ranks=ranks)
+            return DistComm(g) if rank in ranks else None
+        # 'hybrid' (default): CFG halves x frame groups -- 8 GPUs = 2 x (7/6/6/6); 'frames': 4/3/3/3/3/3/3/3 (BASELINE config 3)
+        shard = make_shard(T, world, rank, mode=args.shard, make_group=make_group)
     net = build_model(args.model_channels)
     w = synth.window_inputs(T=T, H=H, W=W, seed=0)
     cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
@@ -167,14 +173,17 @@ def main():
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (DRY RUN: gloo host-staged transport, ranks share one GPU -- not a result)",
-        "config": {"workload": (f"{world}xMI355X" + (" frame-sharded " + "/".join(str(c) for c in shard.t_counts) if shard else "") +
+        "config": {"workload": (f"{world}xMI355X" + ((" CFG-split x2 x" if shard.cfg_half is not None else "") + " frame-sharded " +
+                                                     "/".join(str(c) for c in shard.t_counts) if shard else "") +
                                 ": 25x576x1024 (latent 25x4x72x128), 50-step EulerEDM, VanillaCFG 2.5 (N=50 images per UNet call), "
                                 "bf16, random-init 1.65B VideoUNet, synthetic latents") if full else
                    f"REDUCED (not the BASELINE config): T={T} latent {H}x{W} model_channels={args.model_channels}",
                    "frames": T, "latent": [4, H, W], "cfg_images_per_call": 2 * T, "sampler": "EulerEDM s_churn=0, 50-step schedule",
                    "windows_per_s": value / 50.0,
-                   "parallelism": "single GPU" if shard is None else f"frame-shard x{world} (spatial half) + pixel-shard x{world} (temporal half), "
-                                  "2 RCCL all-to-alls per block pair, weights replicated"},
+                   "parallelism": "single GPU" if shard is None else
+                   (("CFG halves on 2 rank groups (one output exchange per step) x " if shard.cfg_half is not None else "") +
+                    f"frame-shard x{shard.P} (spatial half) + pixel-shard x{shard.P} (temporal half), 2 RCCL all-to-alls per block pair, "
+                    "weights replicated")},
         "roofline": roofline,
         "step_mfma_frac": (FLOP_PER_STEP_CFG / (ms_per_step * 1e-3) / (MFMA_BF16_PEAK * world)) if full else None,
     }

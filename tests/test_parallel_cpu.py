@@ -75,3 +75,34 @@ def _gloo_worker(rank, world, port, T, S):
 def test_frame_pixel_exchange_gloo_two_processes():
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_gloo_worker, args=(2, port, 5, 16), nprocs=2, join=True)
+
+
+def test_make_shard_hybrid_layout_threads():
+    """8 ranks -> 2 CFG halves x 4 frame ranks (7/6/6/6); partner pairs (i, i+4); exchanges work inside each half."""
+    from vista_amd.parallel import ThreadGroups, make_shard
+    world, T, S, C = 8, 25, 16, 4
+    groups = ThreadGroups()
+    info, errs = [None] * world, []
+    X = torch.randn(1, T, S, C)
+
+    def run(rank):
+        try:
+            sh = make_shard(T, world, rank, mode="hybrid", make_group=groups.make(rank))
+            assert sh.B == 1 and sh.P == 4 and sh.t_counts == [7, 6, 6, 6] and sh.cfg_half == rank // 4 and sh.rank == rank % 4
+            t0, t1 = sh.t_off[sh.rank], sh.t_off[sh.rank + 1]
+            x_f = X[:, t0:t1].reshape(t1 - t0, S, C).contiguous()
+            assert torch.equal(sh.to_frames(sh.to_pixels(x_f), S), x_f)
+            both = sh.exchange_cfg_halves(torch.full((t1 - t0, 2, 1), float(sh.cfg_half)))
+            assert both[:t1 - t0].eq(0).all() and both[t1 - t0:].eq(1).all()
+            info[rank] = sh.local_image_ids()
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            groups.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]
+    assert info[0] == list(range(0, 7)) and info[4] == list(range(0, 7)) and info[1] == list(range(7, 13))
+    assert make_shard(T, 1, 0) is None

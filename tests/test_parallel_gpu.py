@@ -95,3 +95,46 @@ def test_sharded_sampler_matches_golden():
     r = rel_l2(outs[0], g["linear"])
     print(f"[parity] sharded sampler P=2: rel-L2 {r:.3e}")
     assert r <= 4e-2 and torch.equal(outs[0][0], w["cond_frame"][0])
+
+
+@pytest.mark.parametrize("world,mode", [(2, "hybrid"), (4, "hybrid"), (6, "hybrid"), (3, "hybrid")])
+def test_hybrid_cfg_x_frame_sampler_matches_golden(world, mode):
+    """CFG x frame hybrid (make_shard): world=2 -> pure CFG split, 4 -> 2x2, 6 -> 2x3; odd world falls back to frame sharding."""
+    from tests.test_model_gpu import _sampler, tiny_unet
+    from vista_amd import synth
+    from vista_amd.modules.diffusionmodules.denoiser import Denoiser
+    from vista_amd.modules.diffusionmodules.sampling import FusedDenoiser
+    from vista_amd.modules.diffusionmodules.wrappers import OpenAIWrapper
+    from vista_amd.parallel import ThreadGroups, make_shard
+    g = torch.load(os.path.join(GOLD, "sampler_tiny.pt"))
+    net, _ = tiny_unet()
+    T, H, W = g["T"], g["H"], g["W"]
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1, trajectory=TRAJ)
+    den = Denoiser(scaling_config={"target": "vwm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
+    fused = FusedDenoiser(den, OpenAIWrapper(net))
+    cfg = {"target": "vwm.modules.diffusionmodules.guiders.TrianglePredictionGuider", "params": {"num_frames": T, "max_scale": 2.5, "min_scale": 1.0}}
+    groups = ThreadGroups()
+    outs, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            torch.cuda.set_device(0)
+            s = _sampler(cfg)
+            s.shard = make_shard(T, world, rank, mode=mode, make_group=groups.make(rank))
+            cu = lambda d: {k: v.clone().cuda() for k, v in d.items()}  # noqa: E731
+            outs[rank] = s(fused, w["noise"].clone().cuda(), cond=cu(w["c"]), uc=cu(w["uc"]), cond_frame=w["cond_frame"].cuda(),
+                           cond_mask=w["cond_mask"].cuda()).cpu()
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            groups.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0]), "every rank must end with the same window"
+    r = rel_l2(outs[0], g["triangle"])
+    print(f"[parity] hybrid world={world}: rel-L2 {r:.3e}")
+    assert r <= 4e-2 and torch.equal(outs[0][0], w["cond_frame"][0])

@@ -137,9 +137,16 @@ class FusedLoop:
             return a, b
         cu, cc = both("concat")
         self.cu, self.cc = loc(cu.float().contiguous()), loc(cc.float().contiguous())
-        self.ctx2 = torch.cat(both("crossattn"), 0)   # full window (replicated on every rank)
-        self.y2 = torch.cat(both("vector"), 0)
-        self.mask2 = torch.cat([maskf, maskf])
+        self.half = None if shard is None else shard.cfg_half  # CFG x frame hybrid: this rank runs ONE guidance half
+        self.unet_shard = shard if (shard is not None and shard.P > 1) else None  # a 1-rank frame group needs no re-sharding
+        if self.half is None:
+            self.ctx2 = torch.cat(both("crossattn"), 0)   # full window (replicated on every rank)
+            self.y2 = torch.cat(both("vector"), 0)
+            self.mask2 = torch.cat([maskf, maskf])
+        else:
+            self.ctx2 = both("crossattn")[self.half]
+            self.y2 = both("vector")[self.half]
+            self.mask2 = maskf
         self.cf = loc(cond_frame.float().contiguous()) if replace else None
         # EDM coefficients per step on the host (denoiser_scaling.py:51-59): no device round trip inside the loop
         self.coef = [tuple(float(v) for v in self.den.scaling(torch.tensor(s, dtype=torch.float32))) for s in sig[:-1]]
@@ -147,8 +154,15 @@ class FusedLoop:
     def step(self, i):
         c_skip, c_out, c_in, c_noise = self.coef[i]
         net_in = ops.sampler_prepare(self.xw, self.cf, self.maskf, self.cu, self.cc, self.cin_pad, c_in, self.replace)
-        ts = torch.full((2 * self.n,), c_noise, device=self.xw.device)
-        net_out = self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.shard)
+        if self.half is None:
+            ts = torch.full((2 * self.n,), c_noise, device=self.xw.device)
+            net_out = self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.unet_shard)
+        else:  # run this rank's guidance half, then swap outputs with the partner that owns the same frames of the other half
+            tl = self.xw.shape[0]
+            ts = torch.full((self.n,), c_noise, device=self.xw.device)
+            mine = self.unet.forward_tokens(net_in[self.half * tl:(self.half + 1) * tl], ts, self.ctx2, self.y2, self.mask2, self.T,
+                                            self.H, self.W, shard=self.unet_shard)
+            net_out = self.shard.exchange_cfg_halves(mine)
         ops.sampler_update(self.xw, net_out, self.scales, c_out, c_skip, self.sig[i], self.sig[i + 1])
 
     def finish(self):

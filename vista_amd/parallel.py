@@ -35,6 +35,36 @@ def offsets(counts):
     return o
 
 
+class SelfComm:
+    """Single-rank communicator (a frame-shard group of one rank, e.g. the CFG-only split at 2 GPUs)."""
+    rank, world = 0, 1
+
+    def all_to_all(self, recv, send, out_splits, in_splits):
+        recv.copy_(send)
+
+    def all_reduce_sum(self, t):
+        pass
+
+    def all_gather_list(self, t, counts):
+        return [t]
+
+
+def make_shard(T, world, rank, mode="hybrid", make_group=None):
+    """Build the FrameShard of `rank` in a `world`-rank job. mode 'frames': pure frame sharding (both CFG halves per rank).
+    mode 'hybrid': CFG halves x frame groups when world is even (ranks [0, world/2) = uncond, the rest = cond).
+    make_group(list_of_ranks) -> communicator for that subgroup (must be called collectively, same order on all ranks)."""
+    if world == 1:
+        return None
+    if mode == "frames" or world % 2:
+        return FrameShard(T, make_group(list(range(world))), B=2)
+    half = world // 2
+    groups = [make_group(list(range(h * half, (h + 1) * half))) if half > 1 else None for h in range(2)]
+    pairs = [make_group([i, i + half]) for i in range(half)]
+    h, i = rank // half, rank % half
+    comm = groups[h] if half > 1 else SelfComm()
+    return FrameShard(T, comm, B=1, cfg_pair=pairs[i], cfg_half=h)
+
+
 class DistComm:
     """torch.distributed transport. With the gloo backend (CPU tests, and the single-GPU dry run of bench.py's multi-rank
     path) device tensors are staged through host memory; with "nccl" (= RCCL) they go GPU-to-GPU over xGMI."""
@@ -42,7 +72,7 @@ class DistComm:
     def __init__(self, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)  # rank WITHIN the group
         self.host_staged = dist.get_backend(group) == "gloo"
 
     def all_to_all(self, recv, send, out_splits, in_splits):
@@ -70,6 +100,28 @@ class DistComm:
         outs = [torch.empty_like(pad) for _ in counts]
         self.dist.all_gather(outs, pad, group=self.group)
         return [o[:c].to(dev) for o, c in zip(outs, counts)]
+
+
+class ThreadGroups:
+    """Factory of ThreadComm sub-communicators for a job of thread ranks: `make(rank)` returns the make_group callback of
+    that rank (same contract as the torch.distributed one: called collectively, returns None to non-members)."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.shared = {}
+
+    def make(self, rank):
+        def make_group(ranks):
+            key = tuple(ranks)
+            with self.lock:
+                if key not in self.shared:
+                    self.shared[key] = ThreadComm.Shared(len(ranks))
+            return ThreadComm(self.shared[key], ranks.index(rank)) if rank in ranks else None
+        return make_group
+
+    def abort(self):
+        for sh in self.shared.values():
+            sh.barrier.abort()
 
 
 class ThreadComm:
@@ -125,10 +177,19 @@ class ThreadComm:
 
 
 class FrameShard:
-    """Frame / pixel partition of one sampling window and the exchanges between the two layouts."""
+    """Frame / pixel partition of one sampling window and the exchanges between the two layouts.
 
-    def __init__(self, T, comm, B=2):
+    `cfg_pair` (optional) turns on the CFG x frame hybrid: the classifier-free-guidance halves (uncond / cond) never
+    interact inside the UNet, so world = 2 x P ranks run them on two independent frame-shard groups of P ranks (this
+    object then describes ONE half: B = 1, `comm` = that half's group) and the two ranks that own the same frames
+    exchange their (t_local, S, 4) network outputs once per step through `cfg_pair` (a 2-rank communicator,
+    index 0 = uncond, 1 = cond). 25 frames on 8 GPUs: 2 x (7/6/6/6) instead of 4/3/3/3/3/3/3/3."""
+
+    def __init__(self, T, comm, B=2, cfg_pair=None, cfg_half=None):
         self.T, self.comm, self.B = T, comm, B
+        self.cfg_pair, self.cfg_half = cfg_pair, cfg_half
+        if cfg_pair is not None:
+            assert B == 1 and cfg_half in (0, 1)
         self.P, self.rank = comm.world, comm.rank
         if self.P > T:
             raise ValueError(f"cannot shard {T} frames over {self.P} ranks")
@@ -218,6 +279,11 @@ class FrameShard:
         """Rows of a (B*T, ...) replicated tensor that belong to this rank's images, in local order."""
         idx = torch.tensor(self.local_image_ids(), device=full.device)
         return full.index_select(0, idx)
+
+    def exchange_cfg_halves(self, net_out_half):
+        """Hybrid mode: (t_local, S, C) output of this rank's CFG half -> (2*t_local, S, C) [uncond; cond] on both partners."""
+        halves = self.cfg_pair.all_gather_list(net_out_half.contiguous(), [net_out_half.shape[0]] * 2)
+        return torch.cat(halves, 0)
 
     def take_local_frames(self, full):
         """(T, ...) -> (t_local, ...)."""
