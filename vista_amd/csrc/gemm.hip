@@ -205,21 +205,39 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
     for (int ks = 0; ks < 4; ++ks) frag_off[ks] = ((ks * 2 + lh) ^ sw) << 4;
     const int xrow_off = (xoff + l31) * 128, yrow_off = (yoff + l31) * 128;
 
+    // K-step compute with double-buffered fragments: the ds_read_b128s of k-substep ks+1 are issued BEFORE the MFMAs of
+    // substep ks, so the LDS latency is covered by FX*FY MFMAs instead of being exposed at the head of every substep.
+    auto load_frags = [&](const char* sb, int ks, bf16x8_t* xf, bf16x8_t* yf) {
+#pragma unroll
+        for (int f = 0; f < FX; ++f) xf[f] = *(const bf16x8_t*)(sb + xbase + xrow_off + f * 32 * 128 + frag_off[ks]);
+#pragma unroll
+        for (int f = 0; f < FY; ++f) yf[f] = *(const bf16x8_t*)(sb + ybase + yrow_off + f * 32 * 128 + frag_off[ks]);
+    };
+    auto mma = [&](const bf16x8_t* xf, const bf16x8_t* yf) {
+#pragma unroll
+        for (int fi = 0; fi < FX; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < FY; ++fj)
+                acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+    };
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8_t xf[FX], yf[FY];
-#pragma unroll
-            for (int f = 0; f < FX; ++f) xf[f] = *(const bf16x8_t*)(sb + xbase + xrow_off + f * 32 * 128 + frag_off[ks]);
-#pragma unroll
-            for (int f = 0; f < FY; ++f) yf[f] = *(const bf16x8_t*)(sb + ybase + yrow_off + f * 32 * 128 + frag_off[ks]);
-#pragma unroll
-            for (int fi = 0; fi < FX; ++fi)
-#pragma unroll
-                for (int fj = 0; fj < FY; ++fj)
-                    acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
-        }
+        bf16x8_t xa[FX], ya[FY], xb[FX], yb[FY];
+        // sched_barrier(0) pins the phase order; without it hipcc sinks every read next to its first use again
+        load_frags(sb, 0, xa, ya);
+        load_frags(sb, 1, xb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xa, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(sb, 2, xa, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_frags(sb, 3, xb, yb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xa, ya);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xb, yb);
     };
     const int nk = p.K / BK;
     if (DMA) {
