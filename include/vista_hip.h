@@ -37,6 +37,7 @@ typedef struct VkGemmDesc {
     int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning).
                             Weight rows
                             are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                                                      */
+    void* dbg;           /* tuning only: if non-NULL, per-wave phase timers (u64 x4 per wave, 16 waves per sampled block)  */
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:

@@ -246,11 +246,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         dma_tile(0, 0);
         __syncthreads();
         const bool skip_dma = (p.tile_cfg & 16) != 0;  // timing experiment only (results are wrong): no DMA after tile 0
-        for (int kt = 0; kt < nk; ++kt) {
-            const int stage = kt & 1;
-            if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
-            compute(stage);
-            __syncthreads();
+        if (p.dbg == nullptr) {
+            for (int kt = 0; kt < nk; ++kt) {
+                const int stage = kt & 1;
+                if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
+                compute(stage);
+                __syncthreads();
+            }
+        } else {  // phase timers (s_memtime, shader cycles) per wave: [dma issue, compute, barrier wait, total], tuning only
+            unsigned long long t_dma = 0, t_cmp = 0, t_bar = 0;
+            const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+            for (int kt = 0; kt < nk; ++kt) {
+                const int stage = kt & 1;
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                compute(stage);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                __syncthreads();
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+                t_dma += t1 - t0; t_cmp += t2 - t1; t_bar += t3 - t2;
+            }
+            if (lane == 0 && (blockIdx.x % 97) == 0) {
+                unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)(blockIdx.x / 97) * 16 + wave) * 4;
+                d[0] = t_dma; d[1] = t_cmp; d[2] = t_bar; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
+            }
         }
     } else {
         // register-staged pipeline: prefetch tile kt+1 into VGPRs, compute tile kt, then write the VGPRs to the other stage

@@ -116,9 +116,14 @@ def pack_conv_t3(weight, bias=None, device="cuda"):
 TILE_CFG = 0  # 0 = auto; tests force 1/2/3 to cover every block-tile variant
 
 
+GEMM_DBG = None  # tuning only: a u64 CUDA tensor receiving per-wave phase timers of sampled workgroups
+
+
 def _gemm(desc):
     lib = _lib.load()
     desc.tile_cfg = TILE_CFG
+    if GEMM_DBG is not None:
+        desc.dbg = _p(GEMM_DBG)
     check(lib.vk_gemm_bf16(C.byref(desc), _stream()), "vk_gemm_bf16")
 
 
