@@ -31,6 +31,112 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// Fused epilogue shared by the GEMM kernels. Accumulator element r = 4*g + e of tile (fi,fj): X-row = 32*fi + 8*g + 4*lh + e,
+// Y-row = 32*fj + l31 (X = weights / Y = activations, swapped for EPI_TRANS). MW/NW = wave-tile extents along m / n.
+template <int EPI, bool OUT_F32, int FX, int FY, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh) {
+    constexpr int MW = FM * 32, NW = FN * 32;
+    if (EPI == EPI_LINEAR) {
+        const float* __restrict__ bias = p.bias;
+        const float* __restrict__ rowvec = p.rowvec;
+        const uint16_t* __restrict__ res1 = (const uint16_t*)p.res1;
+        const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
+#pragma unroll
+        for (int fj = 0; fj < FY; ++fj) {
+            const int m = m0 + wm * MW + fj * 32 + l31;
+            if (m >= p.M) continue;
+            const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+#pragma unroll
+            for (int fi = 0; fi < FX; ++fi) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * NW + fi * 32 + 8 * g + 4 * lh;
+                    if (n >= p.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
+                    if (bias) {
+                        const float4 b = *(const float4*)(bias + n);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (rv) {
+                        const float4 b = *(const float4*)(rv + n);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (res1) {
+                        const uint2 r = *(const uint2*)(res1 + (size_t)m * p.ld_res1 + n);
+                        v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                    if (res2) {
+                        const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
+                        v[0] += p.beta * bf16_lo(r.x); v[1] += p.beta * bf16_hi(r.x);
+                        v[2] += p.beta * bf16_lo(r.y); v[3] += p.beta * bf16_hi(r.y);
+                    }
+                    if (OUT_F32) {
+                        *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 o;
+                        o.x = pack_bf16(v[0], v[1]);
+                        o.y = pack_bf16(v[2], v[3]);
+                        *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + n) = o;
+                    }
+                }
+            }
+        }
+    } else if (EPI == EPI_GEGLU) {
+        // packed weight rows: every 64-row wave slice = [32 value rows | 32 gate rows]; fi=0 value, fi=1 gate
+        static_assert(EPI != EPI_GEGLU || FN == 2, "GEGLU packing assumes a 64-column wave tile");
+        const float* __restrict__ bias = p.bias;
+        const int nout = p.N >> 1;
+#pragma unroll
+        for (int fj = 0; fj < FY; ++fj) {
+            const int m = m0 + wm * MW + fj * 32 + l31;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int np = n0 + wn * 64 + 8 * g + 4 * lh;       // packed row of the value part
+                const int nc = (n0 >> 1) + wn * 32 + 8 * g + 4 * lh;  // output column
+                if (nc >= nout) continue;
+                float a[4], gt[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = acc[0][fj][4 * g + e]; gt[e] = acc[1][fj][4 * g + e]; }
+                if (bias) {
+                    const float4 ba = *(const float4*)(bias + np);
+                    const float4 bg = *(const float4*)(bias + np + 32);
+                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                }
+                uint2 o;
+                o.x = pack_bf16(a[0] * gelu_erf_f(gt[0]), a[1] * gelu_erf_f(gt[1]));
+                o.y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
+                *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + nc) = o;
+            }
+        }
+    } else {  // EPI_TRANS: out[img][n][key], key = m % S contiguous
+#pragma unroll
+        for (int fj = 0; fj < FY; ++fj) {
+            const int n = n0 + wn * NW + fj * 32 + l31;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int fi = 0; fi < FX; ++fi) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int m = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh;
+                    if (m >= p.M) continue;
+                    const int img = m / p.S;
+                    const int key = m - img * p.S;
+                    uint2 o;
+                    o.x = pack_bf16(acc[fi][fj][4 * g + 0], acc[fi][fj][4 * g + 1]);
+                    o.y = pack_bf16(acc[fi][fj][4 * g + 2], acc[fi][fj][4 * g + 3]);
+                    *(uint2*)((uint16_t*)p.out + ((size_t)img * p.N + n) * p.S + key) = o;
+                }
+            }
+        }
+    }
+}
+
 __device__ uint4 g_zero16;  // source of the zero fill for out-of-image conv taps on the LDS-DMA path (zero-initialised)
 
 template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN, bool DMA>
@@ -287,107 +393,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         }
     }
 
-    // ------------------------------- epilogue -------------------------------
-    // accumulator element r = 4*g + e of tile (fi,fj): X-row = 32*fi + 8*g + 4*lh + e, Y-row = 32*fj + l31
-    if (EPI == EPI_LINEAR) {
-        const float* __restrict__ bias = p.bias;
-        const float* __restrict__ rowvec = p.rowvec;
-        const uint16_t* __restrict__ res1 = (const uint16_t*)p.res1;
-        const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
-#pragma unroll
-        for (int fj = 0; fj < FY; ++fj) {
-            const int m = m0 + wm * MW + fj * 32 + l31;
-            if (m >= p.M) continue;
-            const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
-#pragma unroll
-            for (int fi = 0; fi < FX; ++fi) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * NW + fi * 32 + 8 * g + 4 * lh;
-                    if (n >= p.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
-                    if (bias) {
-                        const float4 b = *(const float4*)(bias + n);
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    }
-                    if (rv) {
-                        const float4 b = *(const float4*)(rv + n);
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    }
-                    if (res1) {
-                        const uint2 r = *(const uint2*)(res1 + (size_t)m * p.ld_res1 + n);
-                        v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-                    if (res2) {
-                        const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
-                        v[0] += p.beta * bf16_lo(r.x); v[1] += p.beta * bf16_hi(r.x);
-                        v[2] += p.beta * bf16_lo(r.y); v[3] += p.beta * bf16_hi(r.y);
-                    }
-                    if (OUT_F32) {
-                        *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        uint2 o;
-                        o.x = pack_bf16(v[0], v[1]);
-                        o.y = pack_bf16(v[2], v[3]);
-                        *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + n) = o;
-                    }
-                }
-            }
-        }
-    } else if (EPI == EPI_GEGLU) {
-        // packed weight rows: every 64-row wave slice = [32 value rows | 32 gate rows]; fi=0 value, fi=1 gate
-        static_assert(EPI != EPI_GEGLU || FN == 2, "GEGLU packing assumes a 64-column wave tile");
-        const float* __restrict__ bias = p.bias;
-        const int nout = p.N >> 1;
-#pragma unroll
-        for (int fj = 0; fj < FY; ++fj) {
-            const int m = m0 + wm * MW + fj * 32 + l31;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int np = n0 + wn * 64 + 8 * g + 4 * lh;       // packed row of the value part
-                const int nc = (n0 >> 1) + wn * 32 + 8 * g + 4 * lh;  // output column
-                if (nc >= nout) continue;
-                float a[4], gt[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] = acc[0][fj][4 * g + e]; gt[e] = acc[1][fj][4 * g + e]; }
-                if (bias) {
-                    const float4 ba = *(const float4*)(bias + np);
-                    const float4 bg = *(const float4*)(bias + np + 32);
-                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
-                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
-                }
-                uint2 o;
-                o.x = pack_bf16(a[0] * gelu_erf_f(gt[0]), a[1] * gelu_erf_f(gt[1]));
-                o.y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
-                *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + nc) = o;
-            }
-        }
-    } else {  // EPI_TRANS: out[img][n][key], key = m % S contiguous
-#pragma unroll
-        for (int fj = 0; fj < FY; ++fj) {
-            const int n = n0 + wn * NW + fj * 32 + l31;
-            if (n >= p.N) continue;
-#pragma unroll
-            for (int fi = 0; fi < FX; ++fi) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int m = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh;
-                    if (m >= p.M) continue;
-                    const int img = m / p.S;
-                    const int key = m - img * p.S;
-                    uint2 o;
-                    o.x = pack_bf16(acc[fi][fj][4 * g + 0], acc[fi][fj][4 * g + 1]);
-                    o.y = pack_bf16(acc[fi][fj][4 * g + 2], acc[fi][fj][4 * g + 3]);
-                    *(uint2*)((uint16_t*)p.out + ((size_t)img * p.N + n) * p.S + key) = o;
-                }
-            }
-        }
-    }
+    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh);
 }
 
 template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
