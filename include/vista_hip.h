@@ -34,9 +34,11 @@ typedef struct VkGemmDesc {
     int32_t amode, epi, out_f32;
     int32_t H, Wd, Cin, Hout, Wout, stride, ups; /* CONV3X3: source H x Wd (before the x`ups` nearest upsample)   */
     int32_t T, S;        /* TEMPORAL3: frames per clip, tokens per frame. EPI_TRANS: S = tokens per image         */
-    int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning).
+    int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning); |16 = timing-only no-DMA experiment.
                             Weight rows
                             are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                                                      */
+    const void* halo_prev; /* TEMPORAL3, frame-sharded runs: bf16 [clips][S][Cin] frame preceding / following the local frame range   */
+    const void* halo_next; /* (from the neighbour rank); NULL = the conv's zero padding at the window ends                               */
     void* dbg;           /* tuning only: if non-NULL, per-wave phase timers (u64 x4 per wave, 16 waves per sampled block)  */
 } VkGemmDesc;
 

@@ -340,9 +340,9 @@ def test_sampler_elementwise():
 
 
 # ------------------------------------------------------------------------------------------------ block-tile variants
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 9, 10, 11, 12])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
 def test_gemm_family_all_tile_configs(cfg):
-    """Every block-tile variant (128x128, 256x128, 256x256, 256x320; +8 = register-staged instead of LDS-DMA) of every loader / epilogue, on shapes with ragged M and N edges."""
+    """Every block-tile variant (128x128, 256x128, 256x256, 256x320) of every loader / epilogue, on shapes with ragged M and N edges."""
     ops = _ops()
     ops.TILE_CFG = cfg
     try:
@@ -379,3 +379,21 @@ def test_gemm_family_all_tile_configs(cfg):
         close(ot, F.conv3d(x5, wt.float(), bt, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(B * T, S2, Ct), f"conv_t3 cfg{cfg}")
     finally:
         ops.TILE_CFG = 0
+
+
+def test_conv_t3_halo_frames_equal_a_longer_clip():
+    """Frame-sharded temporal conv: a 4-frame middle slice with halo frames from its neighbours == the slice of the full-clip conv."""
+    ops = _ops()
+    B, T, S, C = 2, 8, 40, 128
+    x = rnd(B * T, S, C)
+    w = rnd(C, C, 3, 1, 1, scale=(3 * C) ** -0.5, seed=1)
+    b = rnd(C, seed=2).float()
+    pw = ops.pack_conv_t3(w, b)
+    full = ops.conv_t3(x, pw, T, S).view(B, T, S, C)
+    x4 = x.view(B, T, S, C)
+    for t0, t1 in ((0, 3), (3, 7), (7, 8)):
+        loc = x4[:, t0:t1].reshape(B * (t1 - t0), S, C).contiguous()
+        prev = x4[:, t0 - 1].contiguous() if t0 > 0 else None
+        nxt = x4[:, t1].contiguous() if t1 < T else None
+        out = ops.conv_t3(loc, pw, t1 - t0, S, halo_prev=prev, halo_next=nxt).view(B, t1 - t0, S, C)
+        assert torch.equal(out, full[:, t0:t1]), (t0, t1)

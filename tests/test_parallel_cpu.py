@@ -106,3 +106,32 @@ def test_make_shard_hybrid_layout_threads():
     assert not errs, errs[0]
     assert info[0] == list(range(0, 7)) and info[4] == list(range(0, 7)) and info[1] == list(range(7, 13))
     assert make_shard(T, 1, 0) is None
+
+
+@pytest.mark.parametrize("P,T", [(2, 5), (4, 7), (5, 5)])
+def test_halo_exchange_thread_ranks(P, T):
+    """Neighbour boundary frames: prev = last frame of rank r-1, next = first frame of rank r+1, None at the window ends."""
+    B, S, C = 2, 6, 4
+    X = torch.randn(B, T, S, C)
+    shared = ThreadComm.Shared(P)
+    errs = []
+
+    def run(rank):
+        try:
+            sh = FrameShard(T, ThreadComm(shared, rank), B=B)
+            t0, t1 = sh.t_off[rank], sh.t_off[rank + 1]
+            prev, nxt = sh.halo_exchange(X[:, t0:t1].reshape(B * (t1 - t0), S, C).contiguous())
+            assert (prev is None) == (rank == 0) and (nxt is None) == (rank == P - 1)
+            if prev is not None:
+                assert torch.equal(prev, X[:, t0 - 1])
+            if nxt is not None:
+                assert torch.equal(nxt, X[:, t1])
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]

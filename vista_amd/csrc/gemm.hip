@@ -14,8 +14,9 @@
 //   256x128 (8 waves 4x2, wave tile  64x64)  other narrow N
 //   128x128 (4 waves 2x2, wave tile  64x64)  small problems (embedding MLPs, context vectors)
 // LDS: two stages of (A tile + W tile); rows are 128 B (64 bf16) and the 16-B chunk index is XOR-swizzled
-// with (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free. Global->LDS goes through registers
-// (prefetch tile t+1 while computing tile t; one barrier per K-step).
+// with (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free. Tiles stream HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4; the swizzle, the conv gathers and the zero padding live in the per-lane SOURCE address): tile t+1
+// lands while the MFMAs consume tile t, one barrier per K-step, fragment reads double-buffered in registers.
 // The MFMA is issued "swapped" (weights are the row/A operand, activations the column/B operand) so that a lane
 // owns one output row m and 4 consecutive output columns per accumulator quad -> 8-byte bf16x4 stores and
 // per-lane-contiguous fused epilogues (bias, per-image row vector, residuals, GEGLU).
@@ -139,7 +140,7 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
 
 __device__ uint4 g_zero16;  // source of the zero fill for out-of-image conv taps on the LDS-DMA path (zero-initialised)
 
-template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN, bool DMA>
+template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc p) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;              // threads
@@ -169,10 +170,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
     // ---- per-thread global->LDS staging assignment: chunk lc of rows lr + 32*i ----
     const int lc = tid & 7;
     const int lr = tid >> 3;
-    const int st_off = lds_off(lr, lc);  // (row>>1)&7 is invariant under +RPP*i (RPP is a multiple of 16)
     // LDS-DMA (global_load_lds) writes lane l's 16 B at wave_base + 16*l, i.e. row lr, physical slot lc. To land the
     // swizzled image (logical chunk c at slot c ^ ((row>>1)&7)) the lane must FETCH logical chunk lc ^ sw instead.
-    const int lsrc = DMA ? (lc ^ ((lr >> 1) & 7)) : lc;
+    const int lsrc = lc ^ ((lr >> 1) & 7);
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const uint16_t* wptr[WP];
@@ -207,49 +207,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         }
     }
 
-    uint4 ra[AP], rw[WP];
-    int tap = 0, c0 = 0;  // (tap, channel offset) of the current K-step for the conv loaders
-
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK;
-#pragma unroll
-        for (int i = 0; i < WP; ++i) rw[i] = *(const uint4*)(wptr[i] + k0);
-        if (AMODE == AMODE_DENSE) {
-#pragma unroll
-            for (int i = 0; i < AP; ++i) ra[i] = *(const uint4*)(aptr[i] + k0);
-        } else if (AMODE == AMODE_CONV3X3) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            const int sh = p.ups - 1;
-            const int He = p.H << sh, We = p.Wd << sh;
-#pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                const int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
-                const bool ok = a_ok[i] && iy >= 0 && iy < He && ix >= 0 && ix < We;
-                const int sy = iy >> sh, sx = ix >> sh;
-                if (ok) ra[i] = *(const uint4*)(aptr[i] + ((size_t)(sy * p.Wd + sx) * p.Cin + c0));
-                else ra[i] = make_uint4(0, 0, 0, 0);
-            }
-        } else {
-            const int dt = tap - 1;
-#pragma unroll
-            for (int i = 0; i < AP; ++i) {
-                const int t = a_y0[i] + dt;
-                const bool ok = a_ok[i] && t >= 0 && t < p.T;
-                if (ok) ra[i] = *(const uint4*)(aptr[i] + ((ptrdiff_t)dt * p.S * p.Cin + c0));
-                else ra[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
-        c0 += BK;
-        if (c0 >= p.Cin) { c0 = 0; ++tap; }
-    };
-    auto store_tile = [&](int stage) {
-        char* sA = smem + stage * STAGE_BYTES;
-        char* sW = sA + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < AP; ++i) *(uint4*)(sA + st_off + i * RPP * 128) = ra[i];
-#pragma unroll
-        for (int i = 0; i < WP; ++i) *(uint4*)(sW + st_off + i * RPP * 128) = rw[i];
-    };
+    int tap = 0, c0 = 0;  // (tap, channel offset) of the next K-step to stage, for the conv loaders
 
     // direct global -> LDS staging of tile kt into `stage` (one 1-KiB global_load_lds_dwordx4 per wave and 8-row group)
     auto dma_tile = [&](int kt, int stage) {
@@ -278,12 +236,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         } else {
+            // frames before / after the local range come from the neighbour ranks' halo frames ([clips][S][Cin], frame-sharded
+            // multi-GPU runs) or are the conv's zero padding at the ends of the window (halo pointer NULL)
             const int dt = tap - 1;
+            const uint16_t* hprev = (const uint16_t*)p.halo_prev;
+            const uint16_t* hnext = (const uint16_t*)p.halo_next;
 #pragma unroll
             for (int i = 0; i < AP; ++i) {
                 const int t = a_y0[i] + dt;
-                const bool ok = a_ok[i] && t >= 0 && t < p.T;
-                const uint16_t* src = ok ? aptr[i] + ((ptrdiff_t)dt * p.S * p.Cin + c0) : (const uint16_t*)&g_zero16;
+                const uint16_t* src = aptr[i] + ((ptrdiff_t)dt * p.S * p.Cin + c0);
+                if (t < 0) src = hprev ? hprev + (a_x0[i] + c0) : (const uint16_t*)&g_zero16;
+                if (t >= p.T) src = hnext ? hnext + (a_x0[i] + c0) : (const uint16_t*)&g_zero16;
+                if (!a_ok[i]) src = (const uint16_t*)&g_zero16;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         }
@@ -346,50 +310,36 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         mma(xb, yb);
     };
     const int nk = p.K / BK;
-    if (DMA) {
-        // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
-        // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
-        dma_tile(0, 0);
-        __syncthreads();
-        const bool skip_dma = (p.tile_cfg & 16) != 0;  // timing experiment only (results are wrong): no DMA after tile 0
-        if (p.dbg == nullptr) {
-            for (int kt = 0; kt < nk; ++kt) {
-                const int stage = kt & 1;
-                if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
-                compute(stage);
-                __syncthreads();
-            }
-        } else {  // phase timers (s_memtime, shader cycles) per wave: [dma issue, compute, barrier wait, total], tuning only
-            unsigned long long t_dma = 0, t_cmp = 0, t_bar = 0;
-            const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-            for (int kt = 0; kt < nk; ++kt) {
-                const int stage = kt & 1;
-                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
-                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-                compute(stage);
-                __builtin_amdgcn_sched_barrier(0);
-                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-                __syncthreads();
-                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-                t_dma += t1 - t0; t_cmp += t2 - t1; t_bar += t3 - t2;
-            }
-            if (lane == 0 && (blockIdx.x % 97) == 0) {
-                unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)(blockIdx.x / 97) * 16 + wave) * 4;
-                d[0] = t_dma; d[1] = t_cmp; d[2] = t_bar; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
-            }
-        }
-    } else {
-        // register-staged pipeline: prefetch tile kt+1 into VGPRs, compute tile kt, then write the VGPRs to the other stage
-        load_tile(0);
-        store_tile(0);
-        __syncthreads();
+    // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
+    // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
+    dma_tile(0, 0);
+    __syncthreads();
+    const bool skip_dma = (p.tile_cfg & 16) != 0;  // timing experiment only (results are wrong): no DMA after tile 0
+    if (p.dbg == nullptr) {
         for (int kt = 0; kt < nk; ++kt) {
             const int stage = kt & 1;
-            if (kt + 1 < nk) load_tile(kt + 1);
+            if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
             compute(stage);
-            if (kt + 1 < nk) store_tile(stage ^ 1);
             __syncthreads();
+        }
+    } else {  // phase timers (s_memtime, shader cycles) per wave: [dma issue, compute, barrier wait, total], tuning only
+        unsigned long long t_dma = 0, t_cmp = 0, t_bar = 0;
+        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int stage = kt & 1;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            compute(stage);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            t_dma += t1 - t0; t_cmp += t2 - t1; t_bar += t3 - t2;
+        }
+        if (lane == 0 && (blockIdx.x % 97) == 0) {
+            unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)(blockIdx.x / 97) * 16 + wave) * 4;
+            d[0] = t_dma; d[1] = t_cmp; d[2] = t_bar; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
         }
     }
 
@@ -401,10 +351,7 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tilesN = (d->N + BN - 1) / BN;
     const int tilesM = (d->M + BM - 1) / BM;
-    if (d->tile_cfg & 8)  // register-staged variant (A/B testing)
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN, false>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, *d);
-    else
-        hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN, true>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, *d);
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, *d);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
@@ -442,7 +389,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 31) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || (d->tile_cfg & 8) || d->tile_cfg > 31) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;

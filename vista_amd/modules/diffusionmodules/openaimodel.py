@@ -119,10 +119,12 @@ class ResBlock(TimestepBlock, Packable):
             pk["skip"] = ops.pack_linear(self.skip_connection.weight, self.skip_connection.bias, dev)
         return pk
 
-    def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, shard=None, S_total=None):
+    def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, shard=None, T_global=None):
         """x (n_img, S, C) bf16; emb_silu (n_img, emb_channels) bf16 = silu(emb).
         dims=2: returns skip(x) + h.  dims=3 (time_stack): statistics/conv span the T frames of each clip and the result is
-        blend + out_alpha*(conv2 + bias) with blend = x, i.e. AlphaBlender(x_spatial=x, x_temporal=x+h) folded in."""
+        blend + out_alpha*(conv2 + bias) with blend = x, i.e. AlphaBlender(x_spatial=x, x_temporal=x+h) folded in.
+        Multi-GPU (`shard`): x holds T = t_local frames of a T_global-frame clip; the norms all-reduce their partial sums and
+        the convs read the neighbour ranks' boundary frames (halo exchange)."""
         pk = self.packed()
         n_img, S, _ = x.shape
         gn1, gn2 = self.in_layers[0], self.out_layers[0]
@@ -132,9 +134,12 @@ class ResBlock(TimestepBlock, Packable):
         def gnorm(t, gn):
             if shard is None or self.dims == 2:
                 return ops.groupnorm(t, gn.weight, gn.bias, gn.eps, silu=True, frames_per_group=fpg)
-            # pixel-sharded temporal norm: statistics span (C/32, T, all H*W pixels) -> all-reduce the partial sums
-            cnt = float(t.shape[-1] // 32) * float(S_total) * float(T)
+            # frame-sharded temporal norm: statistics span (C/32, ALL T frames, H*W) -> all-reduce the local partial sums
+            cnt = float(t.shape[-1] // 32) * float(S) * float(T_global)
             return ops.groupnorm_sharded(t, gn.weight, gn.bias, gn.eps, True, fpg, shard.all_reduce_sum, cnt)
+
+        def halo(t):
+            return shard.halo_exchange(t) if (shard is not None and self.dims == 3) else (None, None)
         h = gnorm(x, gn1)
         if self.dims == 2:
             h, _, _ = ops.conv3x3(h, pk["conv1"], n_img, H, W, rowvec=emb_out)
@@ -142,9 +147,11 @@ class ResBlock(TimestepBlock, Packable):
             skip = x if "skip" not in pk else ops.linear(x, pk["skip"])
             out, _, _ = ops.conv3x3(h, pk["conv2"], n_img, H, W, res1=skip)
             return out
-        h = ops.conv_t3(h, pk["conv1"], T, S, rowvec=emb_out)
+        prev, nxt = halo(h)
+        h = ops.conv_t3(h, pk["conv1"], T, S, rowvec=emb_out, halo_prev=prev, halo_next=nxt)
         h = gnorm(h, gn2)
-        return ops.conv_t3(h, pk["conv2"], T, S, alpha=out_alpha, res2=x, beta=1.0)
+        prev, nxt = halo(h)
+        return ops.conv_t3(h, pk["conv2"], T, S, alpha=out_alpha, res2=x, beta=1.0, halo_prev=prev, halo_next=nxt)
 
 
 class Timestep(nn.Module):

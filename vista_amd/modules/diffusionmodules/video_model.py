@@ -45,10 +45,8 @@ class VideoResBlock(ResBlock):
         # alpha*x + (1-alpha)*(x + h_t) == x + (1-alpha)*h_t, fused into the last temporal conv's epilogue
         if shard is None:
             return self.time_stack(x, emb_silu, H, W, T=num_frames, out_alpha=1.0 - self._alpha)
-        S = x.shape[1]
-        xp = shard.to_pixels(x)  # (B*T, S_r, C): all frames of this rank's pixels
-        yp = self.time_stack(xp, full["emb_silu"], H, W, T=num_frames, out_alpha=1.0 - self._alpha, shard=shard, S_total=S)
-        return shard.to_frames(yp, S)
+        # frame-sharded: the temporal ResBlock keeps this rank's frames (halo exchange + stats all-reduce inside)
+        return self.time_stack(x, emb_silu, H, W, T=shard.t_local, out_alpha=1.0 - self._alpha, shard=shard, T_global=num_frames)
 
 
 class VideoUNet(nn.Module, Packable):

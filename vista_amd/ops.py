@@ -210,8 +210,9 @@ def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, row
     return out.view(n_img, Hout * Wout, pw.N), Hout, Wout
 
 
-def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0):
-    """3x1x1 temporal conv, pad (1,0,0) (video_model.py:38-52) over x ((b t), S, C)."""
+def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0, halo_prev=None, halo_next=None):
+    """3x1x1 temporal conv, pad (1,0,0) (video_model.py:38-52) over x ((b t), S, C). halo_prev / halo_next: (clips, S, C) frames
+    adjacent to the local frame range (frame-sharded multi-GPU); None = zero padding."""
     _need(x, BF16, "x")
     if not x.is_contiguous():
         raise ValueError("conv_t3: x must be contiguous")
@@ -225,6 +226,12 @@ def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1
     d.A, d.lda = _p(x), cin
     d.amode, d.epi = AMODE_TEMPORAL3, EPI_LINEAR
     d.Cin, d.T, d.S = cin, T, S
+    for name, h in (("halo_prev", halo_prev), ("halo_next", halo_next)):
+        if h is not None:
+            _need(h, BF16, name)
+            if not h.is_contiguous() or h.shape != (x.shape[0] // T, S, cin):
+                raise ValueError(f"{name}: expected contiguous (clips, S, C) = {(x.shape[0] // T, S, cin)}, got {tuple(h.shape)}")
+            setattr(d, name, _p(h))
     _fill_epilogue(d, pw, out, M, rowvec, S, res1, res2, alpha, beta)
     _gemm(d)
     return out.view(x.shape[0], S, pw.N)

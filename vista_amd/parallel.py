@@ -6,12 +6,12 @@ single all-gather is not enough. The partition used here:
 
   spatial half  (2-D ResBlock, spatial transformer block, up/down-sampling, per-image norms, sampler elementwise):
       FRAME-sharded -- rank r owns t_r frames (of both CFG halves), all pixels.           25 -> 4/3/3/3/3/3/3/3 at 8 GPUs
-  temporal half (time_stack ResBlock, VideoTransformerBlock): every op is pointwise in space, so it runs
-      PIXEL-sharded -- rank r owns all T frames of S/P pixels.
-
-`to_pixels` / `to_frames` re-shard with ONE all-to-all each (xGMI is point-to-point: every pair of GPUs exchanges its
-slice directly, all 7 links busy, no ring). The only other collective is a 64-float-per-clip all-reduce of the 5-D
-GroupNorm partial sums. Weights and the (tiny) conditioning tensors are replicated. No collective touches the spatial
+  temporal transformer (VideoTransformerBlock): every op is pointwise in space, so it runs
+      PIXEL-sharded -- rank r owns all T frames of S/P pixels; `to_pixels` / `to_frames` re-shard with ONE all-to-all each
+      (xGMI is point-to-point: every pair of GPUs exchanges its slice directly, no ring).
+  temporal ResBlock (time_stack: GN5d -> 3x1x1 conv -> GN5d -> 3x1x1 conv): stays FRAME-sharded; each conv needs only the
+      neighbour ranks' boundary frame (`halo_exchange`, 2 frames per conv instead of a full re-shard) and each 5-D GroupNorm
+      a 64-float-per-clip all-reduce of its partial sums. Weights and the (tiny) conditioning tensors are replicated. No collective touches the spatial
 half.
 
 Communicators: `DistComm` wraps torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests);
@@ -267,6 +267,31 @@ class FrameShard:
         recv = torch.empty(sum(out_splits), dtype=y.dtype, device=y.device)
         self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
         return recv.view(-1, C).index_select(0, pl["unpack_pf"]).view(B * self.t_local, S, C)
+
+    def halo_exchange(self, h):
+        """Frame-sharded temporal conv support: h (B*t_local, S, C) -> (prev, next), each (B, S, C): the neighbour ranks' last /
+        first frame, or None at the ends of the window (= the conv's zero padding). One sparse all-to-all (only the two
+        neighbour splits are non-empty), 2 frames instead of the (P-1)/P of the whole activation a re-shard moves."""
+        B, t_l, r, P = self.B, self.t_local, self.rank, self.P
+        n, S, C = h.shape
+        assert n == B * t_l
+        h4 = h.view(B, t_l, S, C)
+        fs = B * S * C
+        parts, in_splits, out_splits = [], [0] * P, [0] * P
+        if r > 0:
+            parts.append(h4[:, 0].reshape(-1))
+            in_splits[r - 1] = fs
+            out_splits[r - 1] = fs
+        if r < P - 1:
+            parts.append(h4[:, t_l - 1].reshape(-1))
+            in_splits[r + 1] = fs
+            out_splits[r + 1] = fs
+        send = torch.cat(parts) if parts else h.new_empty(0)
+        recv = torch.empty(sum(out_splits), dtype=h.dtype, device=h.device)
+        self.comm.all_to_all(recv, send, out_splits, in_splits)
+        prev = recv[:fs].view(B, S, C) if r > 0 else None
+        nxt = recv[(fs if r > 0 else 0):(fs if r > 0 else 0) + fs].view(B, S, C) if r < P - 1 else None
+        return prev, nxt
 
     def all_reduce_sum(self, t):
         self.comm.all_reduce_sum(t)
