@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
         } else {  // TEMPORAL3: m = (b*T + t)*S + s
             const int fr = m / p.S;
             a_y0[i] = fr % p.T;  // frame index t
-            a_x0[i] = 0;
+            a_x0[i] = ((fr / p.T) * p.S + (m - fr * p.S)) * p.Cin + lsrc * 8;  // element offset of (clip b, pixel s) in a halo frame
             aptr[i] = Ag + (size_t)m * p.Cin + lsrc * 8;
         }
     }
