@@ -139,6 +139,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         loop.step(i)
+    t_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (before any sync)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -185,6 +186,7 @@ def main():
                     f"frame-shard x{shard.P} (spatial half) + pixel-shard x{shard.P} (temporal half), 2 RCCL all-to-alls per block pair, "
                     "weights replicated")},
         "roofline": roofline,
+        "host_enqueue_ms_per_step": t_enqueue * 1e3 / args.steps,
         "step_mfma_frac": (FLOP_PER_STEP_CFG / (ms_per_step * 1e-3) / (MFMA_BF16_PEAK * world)) if full else None,
     }
     if not args.no_cpu_baseline and rank == 0 and world == 1:

@@ -358,7 +358,7 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
 
 // Tile-shape choice (host side, per problem). Preference order: 256x320 (N a multiple of 320, not GEGLU), 256x256 (unless
 // rounding N up to 256 wastes > 10% of the MFMA work), 256x128, 128x128 -- but a variant is only taken if its grid covers the
-// chip (>= 256 workgroups, one per CU; the 128x128 variant runs two per CU). Small-M problems (deep UNet levels, and every
+// chip (>= 192 workgroups, i.e. at least 3/4 of the CUs with one workgroup each; the 128x128 variant runs two per CU). Small-M problems (deep UNet levels, and every
 // level of a frame-sharded multi-GPU run) therefore fall back to smaller tiles instead of leaving CUs idle.
 template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
@@ -370,7 +370,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
         const int n256 = (d->N + 255) / 256 * 256;
         const bool ok320 = (EPI != EPI_GEGLU) && (d->N % 320 == 0);
         const bool ok256 = n256 * 10 <= d->N * 11;
-        const long long need = 256;
+        const long long need = 192;  // >= 75 % of the 256 CUs in a single round still beats the smaller, less efficient tiles
         if (ok320 && wgs(256, 320) >= need) cfg = 4;
         else if (ok256 && wgs(256, 256) >= need) cfg = 3;
         else if (wgs(256, 128) >= need) cfg = 2;
