@@ -12,6 +12,7 @@ Fixtures:
   unet_tiny_t5.pt     VideoUNet(model_channels=64) forward, T=5, CFG batch N=10, latent 16x32, cond_mask e0
   unet_tiny_t25.pt    same network, T=25 (N=50): exercises the 25-frame temporal attention / 5-D GroupNorm sizes
   sampler_tiny.pt     Denoiser + VanillaCFG(2.5) + EulerEDMSampler, 3 steps, T=5, latent 16x32 (+ identity / linear guiders)
+  config1_tiny.pt     BASELINE config 1 in miniature: 1 cond frame -> 25 frames, 10 EDM steps, VanillaCFG 2.5 (stored fp16)
   unet_full_t5.pt     (--full) the shipped 1.65 B-parameter configuration (configs/inference/vista.yaml) at latent 16x32, T=5
 """
 import contextlib
@@ -125,6 +126,17 @@ def main():
     res["rollout3"] = sampler(denoiser, w3["noise"].clone(), cond={k: v.clone() for k, v in w3["c"].items()},
                               uc={k: v.clone() for k, v in w3["uc"].items()}, cond_frame=w3["cond_frame"], cond_mask=w3["cond_mask"]).clone()
     print(f"sampler rollout3: rms {res['rollout3'].pow(2).mean().sqrt():.4f}")
+    # BASELINE config 1 in miniature: 1 cond frame -> 25 frames, 10 EDM steps, VanillaCFG 2.5 (sample.py defaults), fp32 CPU
+    T25 = 25
+    w25 = synth.window_inputs(T=T25, H=H, W=W, seed=23, n_cond=1)
+    den25 = c["Denoiser"](scaling_config={"target": CFG + "denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T25)
+    sampler = c["EulerEDMSampler"](num_steps=10, discretization_config=disc_cfg, guider_config=guiders["vanilla"], s_churn=0.0, s_tmin=0.0,
+                                   s_tmax=999.0, s_noise=1.0, verbose=False, device="cpu")
+    out25 = sampler(lambda x, s_, cc_, m_: den25(wrapper, x, s_, cc_, m_), w25["noise"].clone(), cond={k: v.clone() for k, v in w25["c"].items()},
+                    uc={k: v.clone() for k, v in w25["uc"].items()}, cond_frame=w25["cond_frame"], cond_mask=w25["cond_mask"])
+    torch.save({"out": out25.clone().half(), "T": T25, "H": H, "W": W, "seed_x": 23, "steps": 10, "digest": digest},
+               os.path.join(GOLD, "config1_tiny.pt"))
+    print(f"config1_tiny (25 frames, 10 steps): rms {out25.pow(2).mean().sqrt():.4f}")
     # one plain Denoiser.forward for the boundary test
     sig = torch.full((2 * T,), 5.0)
     x2, s2, c2, m2 = g.VanillaCFG(2.5).prepare_inputs(w["noise"] * 5.0, sig[:T], w["c"], w["cond_mask"], w["uc"])

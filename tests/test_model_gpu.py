@@ -126,6 +126,27 @@ def test_sampler_and_denoiser_vs_reference_golden():
     assert r <= 2.5e-2
 
 
+def test_config1_miniature_25_frames_10_steps_vs_reference_golden():
+    """BASELINE config 1 in miniature: 1 cond frame -> 25 frames, 10 EDM steps, VanillaCFG 2.5, against the real reference sampler's
+    output (CPU fp32, stored fp16). Ten Euler steps compound the per-step bf16 error; tolerance rel-L2 <= 6e-2."""
+    from vista_amd import synth
+    from vista_amd.modules.diffusionmodules.denoiser import Denoiser
+    from vista_amd.modules.diffusionmodules.sampling import FusedDenoiser
+    from vista_amd.modules.diffusionmodules.wrappers import OpenAIWrapper
+    g = torch.load(os.path.join(GOLD, "config1_tiny.pt"))
+    net, _ = tiny_unet()
+    T, H, W = g["T"], g["H"], g["W"]
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1)
+    den = Denoiser(scaling_config={"target": "vwm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
+    s = _sampler({"target": "vwm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 2.5}}, steps=g["steps"])
+    out = s(FusedDenoiser(den, OpenAIWrapper(net)), w["noise"].clone().cuda(), cond=cu(w["c"]), uc=cu(w["uc"]),
+            cond_frame=w["cond_frame"].cuda(), cond_mask=w["cond_mask"].cuda()).cpu()
+    r = rel_l2(out, g["out"].float())
+    print(f"[parity] config-1 miniature (25 frames, 10 steps, CFG 2.5): rel-L2 {r:.4e}")
+    assert torch.isfinite(out).all() and r <= 6e-2 and torch.equal(out[0], w["cond_frame"][0])
+
+
 def test_unet_properties_batch_and_determinism():
     """Size-independent properties: clips in a batch are independent (running [A;B] == running A and B) and repeated runs
     are bitwise identical (every reduction, including the GroupNorm statistics, runs in a fixed order: no atomics).

@@ -108,3 +108,15 @@ def test_oracle_matches_live_reference_block():
                 assert _rel(O.video_resblock(sdp, "rb", x, emb, T), mod(x, emb, T)) < 2e-4
             else:
                 assert _rel(O.spatial_video_transformer(sdp, "st", x, ctx, T, True), mod(x, ctx, None, T)) < 2e-4
+
+
+def test_oracle_config1_miniature_matches_reference_golden():
+    """BASELINE config 1 in miniature (1 cond frame -> 25 frames, 10 EDM steps, CFG 2.5) from the real reference sampler."""
+    g = torch.load(os.path.join(GOLD, "config1_tiny.pt"))
+    sd, _ = _tiny_sd()
+    T, H, W = g["T"], g["H"], g["W"]
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1)
+    with torch.no_grad():
+        out = O.euler_edm_sample(lambda x, s, c, m: O.denoiser_forward(sd, x, s, c, m, T), w["noise"], w["c"], w["uc"], w["cond_frame"],
+                                 w["cond_mask"], g["steps"], scale=2.5)
+    assert _rel(out, g["out"].float()) < 5e-3  # golden stored in fp16
