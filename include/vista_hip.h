@@ -17,7 +17,7 @@ extern "C" {
 #endif
 
 /* ------------------------------------------------------------------ GEMM / implicit-GEMM convolution */
-enum { VK_AMODE_DENSE = 0, VK_AMODE_CONV3X3 = 1, VK_AMODE_TEMPORAL3 = 2 };
+enum { VK_AMODE_DENSE = 0, VK_AMODE_CONV3X3 = 1, VK_AMODE_TEMPORAL3 = 2, VK_AMODE_CONV3D = 3 };
 enum { VK_EPI_LINEAR = 0, VK_EPI_GEGLU = 1, VK_EPI_TRANS = 2 };
 
 typedef struct VkGemmDesc {
@@ -33,7 +33,8 @@ typedef struct VkGemmDesc {
     float alpha, beta;   /* out = alpha*(acc + bias + rowvec + res1) + beta*res2                                  */
     int32_t amode, epi, out_f32;
     int32_t H, Wd, Cin, Hout, Wout, stride, ups; /* CONV3X3: source H x Wd (before the x`ups` nearest upsample)   */
-    int32_t T, S;        /* TEMPORAL3: frames per clip, tokens per frame. EPI_TRANS: S = tokens per image         */
+    int32_t T, S;        /* TEMPORAL3: frames per clip, tokens per frame. EPI_TRANS: S = tokens per image.
+                            CONV3D (3x3x3, pad 1 over [frames][H][Wd][Cin], K = 27*Cin): T = frames per clip        */
     int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning); |16 = timing-only no-DMA experiment.
                             Weight rows
                             are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                                                      */
@@ -65,6 +66,11 @@ int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, 
  * row-major buffer: q at qkv + row*ld + head*64, k at + k_off, v at + v_off. */
 int vk_attn_temporal_bf16(const void* qkv, void* o, int32_t B, int32_t T, int32_t S, int32_t heads, int32_t ld,
                           int32_t k_off, int32_t v_off, int32_t ldo, float scale, void* stream);
+
+/* Row softmax, fp32 scores -> bf16 probabilities: y[r][c] = softmax_c(x[r][:cols]). cols % 4 == 0, cols <= 16384.
+ * Replaces `torch.nn.functional.softmax(w_, dim=2)` of the VAE decoder's single-head AttnBlock
+ * (vwm/modules/diffusionmodules/model.py:160-166); q.k^T (scaled) and P.v run as vk_gemm_bf16 calls either side. */
+int vk_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy, void* stream);
 
 /* ------------------------------------------------------------------ normalisation */
 /* GroupNorm(32 groups) [+ SiLU] over token-major x[n_img][S][C]; statistics span `frames_per_group` consecutive

@@ -120,3 +120,35 @@ def test_oracle_config1_miniature_matches_reference_golden():
         out = O.euler_edm_sample(lambda x, s, c, m: O.denoiser_forward(sd, x, s, c, m, T), w["noise"], w["c"], w["uc"], w["cond_frame"],
                                  w["cond_mask"], g["steps"], scale=2.5)
     assert _rel(out, g["out"].float()) < 5e-3  # golden stored in fp16
+
+
+# ------------------------------------------------------------------------------------ temporal VAE decoder
+def _vae_sd(tag):
+    from oracle.make_golden_vae import TINY
+    from vista_amd.modules.autoencoding.temporal_ae import VideoDecoder
+    dec = VideoDecoder(video_kernel_size=[3, 1, 1] if tag == "k311" else 3, **TINY)
+    shapes = {k: tuple(v.shape) for k, v in dec.state_dict().items()}
+    return synth.seeded_state_dict(shapes, 0), shapes
+
+
+@pytest.mark.parametrize("tag", ["k311", "k333"])
+def test_vae_oracle_matches_reference_decoder_golden(tag):
+    from oracle import vae_oracle as V
+    from oracle.make_golden_vae import latents
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"))
+    sd, shapes = _vae_sd(tag)
+    assert synth.shapes_digest(shapes) == g["digest_" + tag], "decoder state-dict names/shapes drifted from the reference VideoDecoder"
+    with torch.no_grad():
+        out = V.video_decoder(sd, latents(g["T"], g["H"], g["W"], g["seed_z"]), g["T"])
+    assert _rel(out, g["out_" + tag]) < 2e-4
+
+
+def test_vae_oracle_decode_first_stage_matches_reference_chunking():
+    from oracle import vae_oracle as V
+    from oracle.make_golden_vae import latents
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"))
+    sd, _ = _vae_sd("k311")
+    z = latents(11, g["H"], g["W"], 6) * 0.18215
+    with torch.no_grad():
+        assert _rel(V.decode_first_stage(sd, z, n_samples=6), g["dfs_11_n6"].float()) < 5e-3   # golden stored in fp16
+        assert _rel(V.decode_first_stage(sd, z, n_samples=3), g["dfs_11_n3"].float()) < 5e-3

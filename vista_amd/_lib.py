@@ -33,6 +33,7 @@ SIGNATURES = {
     "vk_gemm_bf16": [C.POINTER(VkGemmDesc), _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_temporal_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_softmax_rows_f32_bf16": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "vk_groupnorm_silu_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vk_groupnorm_stats_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vk_groupnorm_apply_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],

@@ -344,6 +344,74 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row softmax for the VAE decoder's single-head 512-wide AttnBlock (vwm/modules/diffusionmodules/model.py:135-182):
+// scores arrive fp32 (already scaled by the GEMM epilogue), probabilities leave as bf16 rows for the P.V GEMM.
+// One 256-thread workgroup per row; a row of up to 16384 columns stays in registers between the max / sum / write passes.
+namespace {
+constexpr int SM_MAXV = 16;  // float4 chunks per thread
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, int cols, long long ldx,
+                                                           long long ldy) {
+    __shared__ float red[8];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float4* xr = (const float4*)(x + (size_t)row * ldx);
+    const int nv = cols >> 2;
+    float4 v[SM_MAXV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+            v[i] = xr[c];
+            mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float L2E = 1.4426950408889634f;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+            v[i].x = __builtin_amdgcn_exp2f((v[i].x - mx) * L2E);
+            v[i].y = __builtin_amdgcn_exp2f((v[i].y - mx) * L2E);
+            v[i].z = __builtin_amdgcn_exp2f((v[i].z - mx) * L2E);
+            v[i].w = __builtin_amdgcn_exp2f((v[i].w - mx) * L2E);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+    uint2* yr = (uint2*)(y + (size_t)row * ldy);
+#pragma unroll
+    for (int i = 0; i < SM_MAXV; ++i) {
+        const int c = tid + i * 256;
+        if (c < nv) {
+            uint2 o;
+            o.x = pack_bf16(v[i].x * inv, v[i].y * inv);
+            o.y = pack_bf16(v[i].z * inv, v[i].w * inv);
+            yr[c] = o;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vk_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols, int64_t ldx, int64_t ldy, void* stream_) {
+    if (!x || !y || rows <= 0 || rows > 0x7fffffffLL || cols <= 0 || (cols & 3) || cols > SM_MAXV * 256 * 4 || (ldx & 3) || (ldy & 3) ||
+        ldx < cols || ldy < cols)
+        return VK_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream_, x, (uint16_t*)y, cols, (long long)ldx,
+                       (long long)ldy);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
 extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
                                     int32_t S, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream_) {
     if (!q || !k || !vt || !o || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;

@@ -5,6 +5,7 @@
 //   CONV3X3    implicit-GEMM 3x3 conv, pad 1, stride 1|2, optional fused nearest x2 upsample of the source
 //                                            (openaimodel.py:198,232 ResBlock convs; :136 Downsample; :100-102 Upsample)
 //   TEMPORAL3  3x1x1 conv over frames, pad (1,0,0)   (video_model.py:38-52 time_stack)
+//   CONV3D     3x3x3 conv over (frames, H, W), pad 1 (temporal VAE decoder: autoencoding/temporal_ae.py:24-37,82-87)
 // W is [Npad][K] with K contiguous (= nn.Linear.weight layout; conv weights are packed [Cout][tap][Cin]).
 //
 // Tiling (template): block tile BM x BN x 64 with WM x WN waves, each wave FM x FN MFMA 32x32x16 bf16 tiles, fp32 accumulate.
@@ -25,7 +26,7 @@
 
 namespace {
 
-enum { AMODE_DENSE = 0, AMODE_CONV3X3 = 1, AMODE_TEMPORAL3 = 2 };
+enum { AMODE_DENSE = 0, AMODE_CONV3X3 = 1, AMODE_TEMPORAL3 = 2, AMODE_CONV3D = 3 };
 enum { EPI_LINEAR = 0, EPI_GEGLU = 1, EPI_TRANS = 2 };
 
 constexpr int BK = 64;
@@ -153,13 +154,14 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
         for (int fj = 0; fj < FY; ++fj) {
             const int n = n0 + wn * NW + fj * 32 + l31;
             if (n >= p.N) continue;
+            const float bn = p.bias ? p.bias[n] : 0.f;  // the lane's output channel (VAE AttnBlock v projection carries a bias)
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 uint2 packed[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    packed[g].x = pack_bf16(acc[fi][fj][4 * g + 0], acc[fi][fj][4 * g + 1]);
-                    packed[g].y = pack_bf16(acc[fi][fj][4 * g + 2], acc[fi][fj][4 * g + 3]);
+                    packed[g].x = pack_bf16(acc[fi][fj][4 * g + 0] + bn, acc[fi][fj][4 * g + 1] + bn);
+                    packed[g].y = pack_bf16(acc[fi][fj][4 * g + 2] + bn, acc[fi][fj][4 * g + 3] + bn);
                     if (!wide) {
                         const int m = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh;
                         if (m >= p.M) continue;
@@ -246,6 +248,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
             a_y0[i] = oy * p.stride - 1;
             a_x0[i] = ox * p.stride - 1;
             aptr[i] = Ag + (size_t)img * p.H * p.Wd * p.Cin + lsrc * 8;
+        } else if (AMODE == AMODE_CONV3D) {  // 3x3x3 conv over (frames, H, W): m = frame*H*W + oy*W + ox, frame = b*T + t
+            const int hw = p.H * p.Wd;
+            const int fr = m / hw;
+            const int rem = m - fr * hw;
+            const int oy = rem / p.Wd, ox = rem - oy * p.Wd;
+            a_y0[i] = (fr << 12) | oy;              // oy, ox < 4096; frame index and in-clip index packed above them
+            a_x0[i] = ((fr % p.T) << 12) | ox;
+            aptr[i] = Ag + lsrc * 8;
         } else {  // TEMPORAL3: m = (b*T + t)*S + s
             const int fr = m / p.S;
             a_y0[i] = fr % p.T;  // frame index t
@@ -280,6 +290,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
                 const bool ok = a_ok[i] && iy >= 0 && iy < He && ix >= 0 && ix < We;
                 const int sy = iy >> sh, sx = ix >> sh;
                 const uint16_t* src = ok ? aptr[i] + ((size_t)(sy * p.Wd + sx) * p.Cin + c0) : (const uint16_t*)&g_zero16;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+            }
+        } else if (AMODE == AMODE_CONV3D) {
+            // tap = kt*9 + ky*3 + kx; zero padding in time (clip ends) and space (video_model-style Conv3d(k=3, pad=1):
+            // vwm/modules/autoencoding/temporal_ae.py:24-37,82-87)
+            const int kt3 = tap / 9, r9 = tap - kt3 * 9;
+            const int ky = r9 / 3, kx = r9 - ky * 3;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int fr = a_y0[i] >> 12, oy = a_y0[i] & 4095;
+                const int t = a_x0[i] >> 12, ox = a_x0[i] & 4095;
+                const int tt = t + kt3 - 1, iy = oy + ky - 1, ix = ox + kx - 1;
+                const bool ok = a_ok[i] && tt >= 0 && tt < p.T && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
+                const uint16_t* src = ok ? aptr[i] + (((size_t)(fr + kt3 - 1) * p.H + iy) * p.Wd + ix) * p.Cin + c0 : (const uint16_t*)&g_zero16;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         } else {
@@ -412,10 +436,11 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
     const int force = d->tile_cfg & 7;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (tests / tuning)
     int cfg = force;
     if (cfg == 4 && EPI == EPI_GEGLU) cfg = 3;  // the GEGLU packing needs 64-column wave tiles
+    if (cfg == 4 && AMODE == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
     if (cfg == 0) {
         auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
         const int n256 = (d->N + 255) / 256 * 256;
-        const bool ok320 = (EPI != EPI_GEGLU) && (d->N % 320 == 0);
+        const bool ok320 = (EPI != EPI_GEGLU) && (AMODE != AMODE_CONV3D) && (d->N % 320 == 0);
         const bool ok256 = n256 * 10 <= d->N * 11;
         const long long need = 192;  // >= 75 % of the 256 CUs in a single round still beats the smaller, less efficient tiles
         if (ok320 && wgs(256, 320) >= need) cfg = 4;
@@ -423,7 +448,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
         else if (wgs(256, 128) >= need) cfg = 2;
         else cfg = 1;
     }
-    if constexpr (EPI != EPI_GEGLU) {
+    if constexpr (EPI != EPI_GEGLU && AMODE != AMODE_CONV3D) {
         if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 5>(d, stream);
     }
     if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 2, 4, 4, 2>(d, stream);
@@ -441,6 +466,8 @@ extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;
     if (d->amode == AMODE_TEMPORAL3 && (d->K != 3 * d->Cin || d->T <= 0 || d->S <= 0)) return VK_EINVAL;
+    if (d->amode == AMODE_CONV3D && (d->K != 27 * d->Cin || d->T <= 0 || d->H <= 0 || d->Wd <= 0 || d->H >= 4096 || d->Wd >= 4096 ||
+                                     (long long)d->M != (long long)(d->M / (d->H * d->Wd)) * d->H * d->Wd)) return VK_EINVAL;
     if (d->rowvec && d->rows_per_vec <= 0) return VK_EINVAL;
     const bool f32 = d->out_f32 != 0;
     switch (d->epi) {
@@ -448,7 +475,8 @@ extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
             if ((d->ldc % 4) != 0) return VK_EINVAL;
             if (d->amode == AMODE_DENSE) return f32 ? launch<AMODE_DENSE, EPI_LINEAR, true>(d, stream) : launch<AMODE_DENSE, EPI_LINEAR, false>(d, stream);
             if (d->amode == AMODE_CONV3X3) return f32 ? launch<AMODE_CONV3X3, EPI_LINEAR, true>(d, stream) : launch<AMODE_CONV3X3, EPI_LINEAR, false>(d, stream);
-            if (d->amode == AMODE_TEMPORAL3 && !f32) return launch<AMODE_TEMPORAL3, EPI_LINEAR, false>(d, stream);
+            if (d->amode == AMODE_TEMPORAL3) return f32 ? launch<AMODE_TEMPORAL3, EPI_LINEAR, true>(d, stream) : launch<AMODE_TEMPORAL3, EPI_LINEAR, false>(d, stream);
+            if (d->amode == AMODE_CONV3D) return f32 ? launch<AMODE_CONV3D, EPI_LINEAR, true>(d, stream) : launch<AMODE_CONV3D, EPI_LINEAR, false>(d, stream);
             return VK_EINVAL;
         case EPI_GEGLU:
             if (d->amode != AMODE_DENSE || f32 || (d->N % 128) != 0) return VK_EINVAL;

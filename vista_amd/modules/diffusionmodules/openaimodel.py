@@ -84,12 +84,13 @@ class ResBlock(TimestepBlock, Packable):
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False, dims=2,
                  use_checkpoint=False, up=False, down=False, kernel_size=3, exchange_temb_dims=False, skip_t_emb=False, causal=False):
         super().__init__()
-        if up or down or use_scale_shift_norm or skip_t_emb or use_conv or causal:
-            raise NotImplementedError("resblock_updown / scale-shift norm / skip_t_emb / causal are not used by Vista")
+        if up or down or use_scale_shift_norm or use_conv or causal:
+            raise NotImplementedError("resblock_updown / scale-shift norm / causal are not used by Vista")
         self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
         self.out_channels = out_channels or channels
         self.use_checkpoint = use_checkpoint
-        self.exchange_temb_dims = exchange_temb_dims
+        self.exchange_temb_dims = exchange_temb_dims and not skip_t_emb
+        self.skip_t_emb = skip_t_emb
         self.dims = dims
         if isinstance(kernel_size, Iterable):
             kernel_size = tuple(kernel_size)
@@ -98,11 +99,13 @@ class ResBlock(TimestepBlock, Packable):
             padding = kernel_size // 2
         if dims == 2 and kernel_size not in (3, (3, 3)):
             raise NotImplementedError("2-D ResBlock kernel must be 3x3")
-        if dims == 3 and tuple(kernel_size) != (3, 1, 1):
-            raise NotImplementedError("3-D ResBlock kernel must be (3,1,1) (video_kernel_size: [3,1,1])")
+        if dims == 3 and kernel_size not in (3, (3, 3, 3), (3, 1, 1)):
+            raise NotImplementedError("3-D ResBlock kernel must be (3,1,1) (video_kernel_size: [3,1,1]) or 3x3x3")
+        self.full3d = dims == 3 and kernel_size != (3, 1, 1)
         self.in_layers = nn.Sequential(normalization(channels), SiLU(), conv_nd(dims, channels, self.out_channels, kernel_size, padding=padding))
         self.updown = False
-        self.emb_layers = nn.Sequential(SiLU(), linear(emb_channels, self.out_channels))
+        # skip_t_emb (openaimodel.py:216-220): the VAE decoder's time_stack has no embedding branch
+        self.emb_layers = None if skip_t_emb else nn.Sequential(SiLU(), linear(emb_channels, self.out_channels))
         self.out_layers = nn.Sequential(normalization(self.out_channels), SiLU(), Dropout(p=dropout),
                                         zero_module(conv_nd(dims, self.out_channels, self.out_channels, kernel_size, padding=padding)))
         if self.out_channels == channels:
@@ -111,10 +114,11 @@ class ResBlock(TimestepBlock, Packable):
             self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
 
     def _pack(self, dev):
-        pc = ops.pack_conv3x3 if self.dims == 2 else ops.pack_conv_t3
+        pc = ops.pack_conv3x3 if self.dims == 2 else (ops.pack_conv3d if self.full3d else ops.pack_conv_t3)
         pk = {"conv1": pc(self.in_layers[2].weight, self.in_layers[2].bias, device=dev),
-              "conv2": pc(self.out_layers[3].weight, self.out_layers[3].bias, device=dev),
-              "emb": ops.pack_linear(self.emb_layers[1].weight, self.emb_layers[1].bias, dev)}
+              "conv2": pc(self.out_layers[3].weight, self.out_layers[3].bias, device=dev)}
+        if self.emb_layers is not None:
+            pk["emb"] = ops.pack_linear(self.emb_layers[1].weight, self.emb_layers[1].bias, dev)
         if not isinstance(self.skip_connection, nn.Identity):
             pk["skip"] = ops.pack_linear(self.skip_connection.weight, self.skip_connection.bias, dev)
         return pk
@@ -129,7 +133,8 @@ class ResBlock(TimestepBlock, Packable):
         n_img, S, _ = x.shape
         gn1, gn2 = self.in_layers[0], self.out_layers[0]
         fpg = 1 if self.dims == 2 else T
-        emb_out = ops.linear(emb_silu, pk["emb"], out_f32=True)  # (n_img, Cout): `emb_layers(emb)[..., None, None]`
+        # (n_img, Cout): `emb_layers(emb)[..., None, None]`; skip_t_emb adds zeros (openaimodel.py:268-269)
+        emb_out = None if self.emb_layers is None else ops.linear(emb_silu, pk["emb"], out_f32=True)
 
         def gnorm(t, gn):
             if shard is None or self.dims == 2:
@@ -147,6 +152,12 @@ class ResBlock(TimestepBlock, Packable):
             skip = x if "skip" not in pk else ops.linear(x, pk["skip"])
             out, _, _ = ops.conv3x3(h, pk["conv2"], n_img, H, W, res1=skip)
             return out
+        if self.full3d:  # 3x3x3 time_stack (VAE decoder with video_kernel_size=3); single-GPU only
+            if shard is not None or emb_out is not None:
+                raise NotImplementedError("3x3x3 time_stack: no frame sharding / embedding branch")
+            h = ops.conv3d(h, pk["conv1"], T, H, W)
+            h = gnorm(h, gn2)
+            return ops.conv3d(h, pk["conv2"], T, H, W, alpha=out_alpha, res2=x, beta=1.0)
         prev, nxt = halo(h)
         h = ops.conv_t3(h, pk["conv1"], T, S, rowvec=emb_out, halo_prev=prev, halo_next=nxt)
         h = gnorm(h, gn2)

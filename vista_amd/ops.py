@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import VkGemmDesc, check
 
-AMODE_DENSE, AMODE_CONV3X3, AMODE_TEMPORAL3 = 0, 1, 2
+AMODE_DENSE, AMODE_CONV3X3, AMODE_TEMPORAL3, AMODE_CONV3D = 0, 1, 2, 3
 EPI_LINEAR, EPI_GEGLU, EPI_TRANS = 0, 1, 2
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -66,12 +66,19 @@ def _finish_pack(w2d, bias, device, geglu=False):
     if bias is not None:
         b = torch.zeros((Np,), dtype=F32, device=device)
         b[:N] = bias.to(device=device, dtype=F32)
-    return PackedWeight(wt, b, N, Kp, geglu)
+    return PackedWeight(wt, b, ceil_to(N, 4), Kp, geglu)  # N % 4 == 0 for the 4-column epilogue quads; the extra rows/bias are zero
 
 
 def pack_linear(weight, bias=None, device="cuda"):
     """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1])."""
     return _finish_pack(weight.detach().reshape(weight.shape[0], -1).float(), None if bias is None else bias.detach().float(), device)
+
+
+def pack_rows_as_weight(t, N, K):
+    """Treat an activation buffer whose first N rows are [N][K] bf16 (K contiguous) as the weight operand of a GEMM
+    (q.k^T and P.v of the VAE decoder's AttnBlock). The caller guarantees the rows up to the next tile boundary are readable."""
+    _need(t, BF16, "t")
+    return PackedWeight(t, None, N, K)
 
 
 def pack_linear_cat(weights, device="cuda"):
@@ -103,10 +110,13 @@ def pack_conv3x3(weight, bias=None, cin_pad=None, device="cuda"):
     return _finish_pack(w.reshape(cout, 9 * cp), None if bias is None else bias.detach().float(), device)
 
 
-def pack_conv_t3(weight, bias=None, device="cuda"):
-    """nn.Conv3d weight [Cout][Cin][3][1][1] -> [Cout][kt][Cin]."""
+def pack_conv_t3(weight, bias=None, device="cuda", cin_pad=None):
+    """nn.Conv3d weight [Cout][Cin][3][1][1] -> [Cout][kt][Cin(_pad)]."""
     w = weight.detach().float()[:, :, :, 0, 0].permute(0, 2, 1).contiguous()
     cout, _, cin = w.shape
+    if cin_pad and cin_pad != cin:
+        w = torch.nn.functional.pad(w, (0, cin_pad - cin))
+        cin = cin_pad
     if cin % 64:
         raise ValueError("temporal conv needs Cin % 64 == 0")
     return _finish_pack(w.reshape(cout, 3 * cin), None if bias is None else bias.detach().float(), device)
@@ -170,15 +180,19 @@ def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=
     return out
 
 
-def linear_vt(x, pw, S):
-    """V^T projection for spatial attention: x (n_img*S, K) -> out (n_img, N, S) bf16 (EPI_TRANS)."""
+def linear_vt(x, pw, S, out=None):
+    """V^T projection for spatial attention: x (n_img*S, K) -> out (n_img, N, S) bf16 = (x @ W^T + bias)^T per image (EPI_TRANS)."""
     _need(x, BF16, "x")
     x2, lda = _rows2d(x, "x")
     M = x2.shape[0]
-    out = torch.empty((M // S, pw.N, S), dtype=BF16, device=x.device)
+    if out is None:
+        out = torch.empty((M // S, pw.N, S), dtype=BF16, device=x.device)
+    elif out.dtype != BF16 or not out.is_contiguous() or out.shape != (M // S, pw.N, S):
+        raise ValueError("linear_vt: out must be contiguous bf16 (n_img, N, S)")
     d = VkGemmDesc()
     d.A, d.lda = _p(x2), lda
     d.amode, d.epi = AMODE_DENSE, EPI_TRANS
+    d.bias = _p(pw.bias)
     d.Wt, d.M, d.N, d.K, d.out, d.ldc, d.S = _p(pw.wt), M, pw.N, pw.K, _p(out), S, S
     d.alpha = 1.0
     _gemm(d)
@@ -207,10 +221,11 @@ def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, row
     d.H, d.Wd, d.Cin, d.Hout, d.Wout, d.stride, d.ups = H, W, cin, Hout, Wout, stride, ups
     _fill_epilogue(d, pw, out, M, rowvec, Hout * Wout, res1, res2, alpha, beta)
     _gemm(d)
-    return out.view(n_img, Hout * Wout, pw.N), Hout, Wout
+    return (out.view(n_img, Hout * Wout, pw.N) if out.is_contiguous() else out), Hout, Wout
 
 
-def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0, halo_prev=None, halo_next=None):
+def conv_t3(x, pw, T, S, *, out=None, out_f32=False, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0, halo_prev=None,
+            halo_next=None):
     """3x1x1 temporal conv, pad (1,0,0) (video_model.py:38-52) over x ((b t), S, C). halo_prev / halo_next: (clips, S, C) frames
     adjacent to the local frame range (frame-sharded multi-GPU); None = zero padding."""
     _need(x, BF16, "x")
@@ -221,7 +236,7 @@ def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1
         raise ValueError("conv_t3: weight K mismatch")
     M = x.shape[0] * x.shape[1]
     if out is None:
-        out = torch.empty((M, pw.N), dtype=BF16, device=x.device)
+        out = torch.empty((M, pw.N), dtype=F32 if out_f32 else BF16, device=x.device)
     d = VkGemmDesc()
     d.A, d.lda = _p(x), cin
     d.amode, d.epi = AMODE_TEMPORAL3, EPI_LINEAR
@@ -235,6 +250,36 @@ def conv_t3(x, pw, T, S, *, out=None, rowvec=None, res1=None, res2=None, alpha=1
     _fill_epilogue(d, pw, out, M, rowvec, S, res1, res2, alpha, beta)
     _gemm(d)
     return out.view(x.shape[0], S, pw.N)
+
+
+def pack_conv3d(weight, bias=None, device="cuda", cin_pad=None):
+    """nn.Conv3d weight [Cout][Cin][3][3][3] -> [Cout][kt][ky][kx][Cin(_pad)] (temporal VAE decoder)."""
+    w = weight.detach().float().permute(0, 2, 3, 4, 1).contiguous()  # Cout, kt, ky, kx, Cin
+    cout, _, _, _, cin = w.shape
+    cp = cin_pad or ceil_to(cin, 64)
+    if cp != cin:
+        w = torch.nn.functional.pad(w, (0, cp - cin))
+    return _finish_pack(w.reshape(cout, 27 * cp), None if bias is None else bias.detach().float(), device)
+
+
+def conv3d(x, pw, T, H, W, *, out=None, out_f32=False, res1=None, res2=None, alpha=1.0, beta=0.0):
+    """3x3x3 conv, pad 1, over x ((b t), H*W, Cin) with clips of T frames (AE3DConv.time_mix_conv and the decoder's time_stack)."""
+    _need(x, BF16, "x")
+    if not x.is_contiguous():
+        raise ValueError("conv3d: x must be contiguous")
+    cin = x.shape[-1]
+    if pw.K != 27 * cin:
+        raise ValueError(f"conv3d: weight K {pw.K} != 27*{cin}")
+    M = x.shape[0] * H * W
+    if out is None:
+        out = torch.empty((M, pw.N), dtype=F32 if out_f32 else BF16, device=x.device)
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x), cin
+    d.amode, d.epi = AMODE_CONV3D, EPI_LINEAR
+    d.H, d.Wd, d.Cin, d.T = H, W, cin, T
+    _fill_epilogue(d, pw, out, M, None, 0, res1, res2, alpha, beta)
+    _gemm(d)
+    return out.view(x.shape[0], H * W, -1) if out.dim() == 2 and out.is_contiguous() else out
 
 
 # ---------------------------------------------------------------------------------------------- attention
@@ -270,6 +315,18 @@ def attn_temporal(qkv, B, T, S, heads, scale=None):
 
 
 # ---------------------------------------------------------------------------------------------- norms
+def softmax_rows(x, out=None):
+    """x (rows, cols) fp32 (row stride may exceed cols) -> bf16 softmax over the last dim (VAE decoder AttnBlock)."""
+    _need(x, F32, "x")
+    rows, cols = x.shape
+    if x.stride(1) != 1:
+        raise ValueError("softmax_rows: rows must be contiguous")
+    if out is None:
+        out = torch.empty((rows, cols), dtype=BF16, device=x.device)
+    check(_lib.load().vk_softmax_rows_f32_bf16(_p(x), _p(out), rows, cols, x.stride(0), out.stride(0), _stream()), "vk_softmax_rows_f32_bf16")
+    return out
+
+
 def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None):
     """x (n_img, S, C) bf16 contiguous."""
     _need(x, BF16, "x")

@@ -63,3 +63,13 @@ def repeat_as_img_seq(x, num_frames):
             new_x += [item_x] * num_frames
         return new_x
     return x.repeat_interleave(num_frames, dim=0)
+
+
+def partialclass(cls, *args, **kwargs):
+    """vwm/util.py partialclass: a subclass whose __init__ has the given arguments pre-bound."""
+    import functools
+
+    class NewCls(cls):
+        __init__ = functools.partialmethod(cls.__init__, *args, **kwargs)
+
+    return NewCls
