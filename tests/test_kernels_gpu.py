@@ -232,7 +232,9 @@ def test_attn_temporal(B, T, S, heads):
 
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("n,S,C,fpg,silu,eps", [(4, 144, 320, 1, True, 1e-5), (6, 100, 64, 1, False, 1e-6), (6, 64, 192, 3, True, 1e-5),
-                                                 (2, 576, 960, 1, True, 1e-5), (50, 16, 2560, 25, True, 1e-5), (2, 300, 1920, 2, False, 1e-5)])
+                                                 (2, 576, 960, 1, True, 1e-5), (50, 16, 2560, 25, True, 1e-5), (2, 300, 1920, 2, False, 1e-5),
+                                                 # > 256 partials per group: the two-level finalize (VAE decoder's 576x1024 levels)
+                                                 (2, 40000, 64, 1, True, 1e-6), (10, 9216, 64, 5, True, 1e-5), (3, 33000, 128, 3, False, 1e-5)])
 def test_groupnorm(n, S, C, fpg, silu, eps):
     ops = _ops()
     x = (rnd(n, S, C).float() * 1.5 + 0.7).to(BF16)

@@ -80,12 +80,33 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restric
 // stats pass 2: one workgroup per image-group; sums the (frames_per_group x chunks) partials of each of the 64 values
 // in a fixed order (4 strided lanes per value, then a fixed 4-way combine) and writes the raw [32 sums | 32 sums of squares]
 // (kept raw so that a pixel-sharded multi-GPU run can all-reduce them before the apply pass).
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nparts) {
+//
+// Large images (the VAE decoder's 576x1024 levels have up to 64512 partials per group) take it in two fixed-order levels:
+// level 1 (gridDim.y = splits > 1) folds `per` consecutive partials into the slot of the first one, in place -- a workgroup
+// reads only its own range before it writes -- and gn_finalize_level2_kernel sums those slots (`per` partials apart).
+__global__ void gn_finalize_kernel(float* __restrict__ partial, float* __restrict__ sums, int nparts, int per, int in_place) {
     __shared__ float red[4][64];
     const int v = threadIdx.x & 63, j = threadIdx.x >> 6;  // 256 threads
+    const int first = blockIdx.y * per;
+    const int cnt = min(per, nparts - first);
+    float* src = partial + ((size_t)blockIdx.x * nparts + first) * 64 + v;
+    float a = 0.f;
+    for (int i = j; i < cnt; i += 4) a += src[(size_t)i * 64];
+    red[j][v] = a;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float t = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
+        if (in_place) src[0] = t;
+        else sums[(size_t)blockIdx.x * 64 + v] = t;
+    }
+}
+
+__global__ void gn_finalize_level2_kernel(const float* __restrict__ partial, float* __restrict__ sums, int nparts, int per, int splits) {
+    __shared__ float red[4][64];
+    const int v = threadIdx.x & 63, j = threadIdx.x >> 6;
     const float* src = partial + (size_t)blockIdx.x * nparts * 64 + v;
     float a = 0.f;
-    for (int i = j; i < nparts; i += 4) a += src[(size_t)i * 64];
+    for (int i = j; i < splits; i += 4) a += src[(size_t)i * per * 64];
     red[j][v] = a;
     __syncthreads();
     if (threadIdx.x < 64) sums[(size_t)blockIdx.x * 64 + v] = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
@@ -240,7 +261,19 @@ extern "C" int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partia
     const size_t lds_bytes = (size_t)2 * g.R * C * sizeof(float);
     hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, partial_ws, S, C, g.CG, g.R);
     VK_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(g.ngroups), dim3(256), 0, stream, (const float*)partial_ws, sums, frames_per_group * g.nchunks);
+    const int nparts = frames_per_group * g.nchunks;
+    if (nparts <= 256) {
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(g.ngroups), dim3(256), 0, stream, partial_ws, sums, nparts, nparts, 0);
+    } else {
+        int per = 16;
+        while ((long long)per * per < nparts) per += 4;  // ~sqrt(nparts), a multiple of the 4 accumulation lanes
+        const int splits = (nparts + per - 1) / per;
+        // level 1: partial[g][k*per] <- sum of partial[g][k*per .. k*per+per)
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(g.ngroups, splits), dim3(256), 0, stream, partial_ws, sums, nparts, per, 1);
+        VK_CHECK_LAUNCH();
+        // level 2: sums[g] <- sum over the `splits` slots, which sit `per` partials apart (group stride = nparts partials)
+        hipLaunchKernelGGL(gn_finalize_level2_kernel, dim3(g.ngroups), dim3(256), 0, stream, (const float*)partial_ws, sums, nparts, per, splits);
+    }
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
