@@ -4,6 +4,7 @@ PyTorch is used for device memory (caching allocator), streams and views only; e
 hand-written gfx950 kernel in libvista_hip.so. Activations are token-major bf16: (n_img, S=H*W, C), C contiguous.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -124,6 +125,7 @@ def pack_conv_t3(weight, bias=None, device="cuda", cin_pad=None):
 
 # ---------------------------------------------------------------------------------------------- GEMM family
 TILE_CFG = 0  # 0 = auto; tests force 1/2/3 to cover every block-tile variant
+TILE_FLAGS = int(os.environ.get("VISTA_TILE_FLAGS", "0"))  # tuning: 8 = ping-pong schedule, 16 = no-DMA timing experiment
 
 
 GEMM_DBG = None  # tuning only: a u64 CUDA tensor receiving per-wave phase timers of sampled workgroups
@@ -131,7 +133,7 @@ GEMM_DBG = None  # tuning only: a u64 CUDA tensor receiving per-wave phase timer
 
 def _gemm(desc):
     lib = _lib.load()
-    desc.tile_cfg = TILE_CFG
+    desc.tile_cfg = TILE_CFG | TILE_FLAGS
     if GEMM_DBG is not None:
         desc.dbg = _p(GEMM_DBG)
     check(lib.vk_gemm_bf16(C.byref(desc), _stream()), "vk_gemm_bf16")
