@@ -18,7 +18,7 @@ def decode_first_stage(decoder, z, scale_factor=0.18215, en_and_decode_n_samples
     vwm/models/autoencoder.py:206-208.)"""
     z = z / scale_factor
     n_samples = z.shape[0] if en_and_decode_n_samples_a_time is None else en_and_decode_n_samples_a_time
-    video = isinstance(decoder, VideoDecoder)
+    video = isinstance(decoder, VideoDecoder) or getattr(decoder, "is_video_decoder", False)  # the flag lets a test stand in an oracle
     all_out = []
     if overlap < n_samples:
         previous_z = z[:overlap]
