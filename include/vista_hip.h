@@ -41,6 +41,8 @@ typedef struct VkGemmDesc {
     const void* halo_prev; /* TEMPORAL3, frame-sharded runs: bf16 [clips][S][Cin] frame preceding / following the local frame range   */
     const void* halo_next; /* (from the neighbour rank); NULL = the conv's zero padding at the window ends                               */
     void* dbg;           /* tuning only: if non-NULL, per-wave phase timers (u64 x4 per wave, 16 waves per sampled block)  */
+    int32_t asym_pad;    /* CONV3X3: 0 = zero padding 1 on all sides; 1 = padding (0,1,0,1) = bottom/right only, the VAE encoder's
+                            Downsample (vwm/modules/diffusionmodules/model.py:77-81: F.pad(x, (0,1,0,1)) then conv stride 2 pad 0)  */
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
@@ -151,6 +153,13 @@ int vk_mask_replace(const float* x, const float* cond, const float* mask, float*
                     void* stream);
 /* out = x * s[n]  (per-image scale, NCHW f32; denoiser.py:35 `noised_input * c_in`) */
 int vk_scale_rows(const float* x, const float* s, float* out, int32_t n_img, int32_t chw, void* stream);
+
+/* Diagonal-Gaussian posterior of the first-stage encoder (vwm/modules/distributions/distributions.py:24-37 and
+ * regularizers/__init__.py:30-39), fused with encode_first_stage's `z * scale_factor` (vwm/models/diffusion.py:194):
+ * moments f32 NCHW [n][2C][hw] = (mean | logvar); out[n][C][hw] = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale;
+ * noise NULL = the posterior mode (mean * scale). */
+int vk_gaussian_sample(const float* moments, const float* noise, float* out, int32_t n_img, int32_t C, int32_t hw, float scale,
+                       void* stream);
 
 /* library info */
 int vk_abi_version(void);

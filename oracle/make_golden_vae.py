@@ -34,6 +34,10 @@ def latents(n, h, w, seed):
     return synth.seeded_tensor("vae.z", (n, 4, h, w), seed)
 
 
+def images(n, h, w, seed):
+    return torch.tanh(synth.seeded_tensor("vae.img", (n, 3, h, w), seed))
+
+
 def ref_decoder(video_kernel_size, seed=0):
     ref_shim.install()
     with contextlib.redirect_stdout(io.StringIO()):
@@ -75,6 +79,21 @@ def main():
                 res["dfs_11_n3"] = fn(me, z9).clone()
             print("decode_first_stage", tuple(res["dfs_11_n6"].shape), float(res["dfs_11_n6"].pow(2).mean().sqrt()),
                   float((res["dfs_11_n6"] - res["dfs_11_n3"]).abs().max()))
+    # ---- encoder (vwm.modules.diffusionmodules.model.Encoder) + DiagonalGaussianRegularizer, composed as
+    # AutoencodingEngine.encode does (autoencoder.py:193-204; the engine class itself needs pytorch_lightning)
+    with contextlib.redirect_stdout(io.StringIO()):
+        from vwm.modules.autoencoding.regularizers import DiagonalGaussianRegularizer
+        from vwm.modules.diffusionmodules.model import Encoder
+        enc = Encoder(**TINY).eval()
+    eshapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(synth.seeded_state_dict(eshapes, 0), strict=True)
+    x = images(5, 64, 128, 7)
+    res["digest_enc"] = synth.shapes_digest(eshapes)
+    res["enc_moments"] = enc(x).clone()
+    torch.manual_seed(1234)
+    res["enc_z_sampled"] = DiagonalGaussianRegularizer(sample=True)(res["enc_moments"])[0].clone()
+    res["enc_z_mode"] = DiagonalGaussianRegularizer(sample=False)(res["enc_moments"])[0].clone()
+    print("encoder moments", tuple(res["enc_moments"].shape), "rms", float(res["enc_moments"].pow(2).mean().sqrt()))
     torch.save({k: (v.half() if k.startswith("dfs") else v) for k, v in res.items()}, os.path.join(GOLD, "vae_tiny.pt"))  # clip outputs fp32
     print("vae_tiny.pt written", os.path.getsize(os.path.join(GOLD, "vae_tiny.pt")) // 1024, "KiB")
 

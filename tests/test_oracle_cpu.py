@@ -152,3 +152,20 @@ def test_vae_oracle_decode_first_stage_matches_reference_chunking():
     with torch.no_grad():
         assert _rel(V.decode_first_stage(sd, z, n_samples=6), g["dfs_11_n6"].float()) < 5e-3   # golden stored in fp16
         assert _rel(V.decode_first_stage(sd, z, n_samples=3), g["dfs_11_n3"].float()) < 5e-3
+
+
+def test_vae_oracle_encoder_matches_reference_golden():
+    from oracle import vae_oracle as V
+    from oracle.make_golden_vae import TINY, images
+    from vista_amd.modules.diffusionmodules.model import Encoder
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"))
+    shapes = {k: tuple(v.shape) for k, v in Encoder(**TINY).state_dict().items()}
+    assert synth.shapes_digest(shapes) == g["digest_enc"], "encoder state-dict names/shapes drifted from the reference Encoder"
+    sd = synth.seeded_state_dict(shapes, 0)
+    with torch.no_grad():
+        m = V.encoder(sd, images(5, 64, 128, 7))
+    assert _rel(m, g["enc_moments"]) < 2e-4
+    torch.manual_seed(1234)
+    noise = torch.randn(5, 4, 8, 16)  # what DiagonalGaussianDistribution.sample drew under the same seed
+    assert _rel(V.gaussian_sample(m, noise), g["enc_z_sampled"]) < 2e-4
+    assert _rel(V.gaussian_sample(m), g["enc_z_mode"]) < 2e-4

@@ -210,3 +210,63 @@ def test_decoder_refuses_cpu():
     dec = VideoDecoder(video_kernel_size=[3, 1, 1], **TINY)
     with pytest.raises(Exception):
         dec(torch.zeros(1, 4, 8, 8), timesteps=1)
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+@pytest.mark.parametrize("n,H,W,C,Cout", [(2, 8, 16, 64, 64), (1, 10, 6, 128, 192), (3, 16, 16, 64, 128)])
+def test_conv3x3_stride2_asymmetric_pad(n, H, W, C, Cout):
+    """Downsample of the VAE encoder: F.pad(x, (0,1,0,1)) then conv 3x3 stride 2 pad 0 (model.py:77-81)."""
+    ops = _ops()
+    x = rnd(n, H * W, C)
+    w = rnd(Cout, C, 3, 3, scale=(9 * C) ** -0.5, seed=1)
+    b = rnd(Cout, seed=2).float()
+    out, Ho, Wo = ops.conv3x3(x, ops.pack_conv3x3(w, b), n, H, W, stride=2, asym_pad=True)
+    xi = x.float().view(n, H, W, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.pad(xi, (0, 1, 0, 1)), w.float(), b, stride=2)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    close(out, ref.permute(0, 2, 3, 1).reshape(n, Ho * Wo, Cout), "asym-pad stride-2 conv")
+
+
+def test_gaussian_sample_kernel():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    mom = torch.randn(3, 8, 5, 7, generator=g)
+    mom[0, 4:] = 50.0    # logvar clamps at 20
+    mom[1, 4:] = -50.0   # and at -30
+    noise = torch.randn(3, 4, 5, 7, generator=g)
+    mean, logvar = mom[:, :4], mom[:, 4:].clamp(-30, 20)
+    ref = (mean + torch.exp(0.5 * logvar) * noise) * 0.18215
+    out = ops.gaussian_sample(mom.cuda(), noise.cuda(), 0.18215).cpu()
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ops.gaussian_sample(mom.cuda(), None, 2.0).cpu(), mean * 2.0, rtol=1e-6, atol=0)
+
+
+def test_encoder_and_encode_first_stage_match_reference_golden():
+    from oracle.make_golden_vae import TINY, images
+    from vista_amd import synth
+    from vista_amd.models.autoencoder import AutoencodingEngine
+    from vista_amd.models.diffusion import encode_first_stage
+    from vista_amd.modules.diffusionmodules.model import Encoder
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"))
+    enc = Encoder(**TINY)
+    shapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    assert synth.shapes_digest(shapes) == g["digest_enc"]
+    enc.load_state_dict(synth.seeded_state_dict(shapes, 0), strict=True)
+    enc.cuda()
+    x = images(5, 64, 128, 7).cuda()
+    m = enc(x)
+    e = rel_l2(m, g["enc_moments"])
+    print(f"Encoder moments vs reference golden: rel-L2 {e:.3e}")
+    assert m.shape == g["enc_moments"].shape and e < TOL
+    fs = AutoencodingEngine(encoder=enc)
+    torch.manual_seed(1234)
+    noise = torch.randn(5, 4, 8, 16)
+    fs.regularization.noise_fn = lambda shape, device: noise[:shape[0]].to(device)  # the draw the reference made under this seed
+    z = encode_first_stage(fs, x[:3], scale_factor=0.18215, en_and_decode_n_samples_a_time=3)
+    ez = rel_l2(z, g["enc_z_sampled"][:3] * 0.18215)
+    print(f"encode_first_stage (sampled posterior) vs reference: rel-L2 {ez:.3e}")
+    assert z.shape == (3, 4, 8, 16) and ez < TOL
+    fs.regularization.sample = False
+    assert rel_l2(encode_first_stage(fs, x, 1.0, 2), g["enc_z_mode"]) < TOL  # 3 chunks (2, 2, 1), posterior mode
+    with pytest.raises(Exception):
+        enc(torch.zeros(1, 3, 16, 16))

@@ -189,6 +189,21 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, const float* __re
     GRID_STRIDE(i, n) { out[i] = x[i] * s[(int)(i / chw)]; }
 }
 
+__global__ void gaussian_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float* __restrict__ out,
+                                       int n_img, int chw, float scale) {
+    const long long n = (long long)n_img * chw;
+    GRID_STRIDE(i, n) {
+        const long long img = i / chw, r = i - img * chw;
+        const float mean = mom[img * 2 * chw + r];
+        float v = mean;
+        if (noise) {
+            const float lv = fminf(fmaxf(mom[img * 2 * chw + chw + r], -30.f), 20.f);
+            v = fmaf(__expf(0.5f * lv), noise[i], mean);
+        }
+        out[i] = v * scale;
+    }
+}
+
 }  // namespace
 
 #define EW_LAUNCH(kernel, count, ...)                                                                          \
@@ -258,5 +273,10 @@ extern "C" int vk_mask_replace(const float* x, const float* cond, const float* m
 extern "C" int vk_scale_rows(const float* x, const float* s, float* out, int32_t n_img, int32_t chw, void* stream) {
     if (!x || !s || !out || n_img <= 0 || chw <= 0) return VK_EINVAL;
     EW_LAUNCH(scale_rows_kernel, (long long)n_img * chw, x, s, out, n_img, chw);
+}
+extern "C" int vk_gaussian_sample(const float* moments, const float* noise, float* out, int32_t n_img, int32_t C, int32_t hw, float scale,
+                                  void* stream) {
+    if (!moments || !out || n_img <= 0 || C <= 0 || hw <= 0) return VK_EINVAL;
+    EW_LAUNCH(gaussian_sample_kernel, (long long)n_img * C * hw, moments, noise, out, n_img, C * hw, scale);
 }
 extern "C" int vk_abi_version(void) { return 1; }

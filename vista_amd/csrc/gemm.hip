@@ -245,8 +245,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc 
             const int img = m / hw;
             const int rem = m - img * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            a_y0[i] = oy * p.stride - 1;
-            a_x0[i] = ox * p.stride - 1;
+            a_y0[i] = oy * p.stride - (p.asym_pad ? 0 : 1);  // asym_pad: padding only below / right of the image
+            a_x0[i] = ox * p.stride - (p.asym_pad ? 0 : 1);
             aptr[i] = Ag + (size_t)img * p.H * p.Wd * p.Cin + lsrc * 8;
         } else if (AMODE == AMODE_CONV3D) {  // 3x3x3 conv over (frames, H, W): m = frame*H*W + oy*W + ox, frame = b*T + t
             const int hw = p.H * p.Wd;

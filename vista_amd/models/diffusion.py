@@ -40,3 +40,12 @@ def decode_first_stage(decoder, z, scale_factor=0.18215, en_and_decode_n_samples
             out = decoder(current_z, **({"timesteps": current_z.shape[0]} if video else {}))
             all_out.append(out)
     return torch.cat(all_out, dim=0)
+
+
+@torch.no_grad()
+def encode_first_stage(first_stage_model, x, scale_factor=0.18215, en_and_decode_n_samples_a_time=14):
+    """Images (frames, 3, H, W) in [-1, 1] -> latents (frames, 4, H/8, W/8) * scale_factor, `en_and_decode_n_samples_a_time`
+    frames per encoder call (vwm/models/diffusion.py:182-195). `first_stage_model.encode(x)` as in autoencoder.py:188-204."""
+    n_samples = x.shape[0] if en_and_decode_n_samples_a_time is None else en_and_decode_n_samples_a_time
+    outs = [first_stage_model.encode(x[i:i + n_samples], scale=scale_factor) for i in range(0, x.shape[0], n_samples)]
+    return torch.cat(outs, dim=0)

@@ -37,6 +37,23 @@ class Upsample(nn.Module, Packable):
         return ops.conv3x3(x, self.packed(), x.shape[0], H, W, ups=2)
 
 
+class Downsample(nn.Module, Packable):
+    """model.py:69-84: F.pad(x, (0,1,0,1)) then conv3x3 stride 2 pad 0 -- one implicit-GEMM launch with bottom/right padding."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        if not with_conv:
+            raise NotImplementedError("Vista's encoder uses resamp_with_conv=True")
+        self.with_conv = with_conv
+        self.conv = ConvNd(in_channels, in_channels, (3, 3), stride=2, padding=0)
+
+    def _pack(self, dev):
+        return ops.pack_conv3x3(self.conv.weight, self.conv.bias, device=dev)
+
+    def forward(self, x, H, W):
+        return ops.conv3x3(x, self.packed(), x.shape[0], H, W, stride=2, asym_pad=True)
+
+
 class ResnetBlock(nn.Module, Packable):
     """model.py:87-135 with temb_channels=0 (the decoder passes temb=None)."""
 
@@ -204,6 +221,75 @@ class Decoder(nn.Module, Packable):
                 h, H, W = self.up[i_level].upsample(h, H, W)
         h = ops.groupnorm(h, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps, silu=True)
         return self.conv_out(h, H, W, **kwargs)
+
+
+class Encoder(nn.Module, Packable):
+    """model.py:445-558. forward(x NCHW fp32 images in [-1, 1]) -> NCHW fp32 moments (2*z_channels when double_z)."""
+
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0, resamp_with_conv=True,
+                 in_channels, resolution, z_channels, double_z=True, use_linear_attn=False, attn_type="vanilla", **ignore_kwargs):
+        super().__init__()
+        if use_linear_attn:
+            raise NotImplementedError("linear attention is not used by Vista's first stage")
+        self.ch, self.temb_ch = ch, 0
+        self.num_resolutions = len(ch_mult)
+        self.num_res_blocks = num_res_blocks
+        self.resolution, self.in_channels = resolution, in_channels
+        self.conv_in = ConvNd(in_channels, self.ch, (3, 3), padding=1)
+        curr_res = resolution
+        in_ch_mult = (1,) + tuple(ch_mult)
+        self.in_ch_mult = in_ch_mult
+        self.down = nn.ModuleList()
+        for i_level in range(self.num_resolutions):
+            block, attn = nn.ModuleList(), nn.ModuleList()
+            block_in = ch * in_ch_mult[i_level]
+            block_out = ch * ch_mult[i_level]
+            for _ in range(self.num_res_blocks):
+                block.append(ResnetBlock(in_channels=block_in, out_channels=block_out, temb_channels=self.temb_ch, dropout=dropout))
+                block_in = block_out
+                if curr_res in attn_resolutions:
+                    attn.append(make_attn(block_in, attn_type=attn_type))
+            down = nn.Module()
+            down.block, down.attn = block, attn
+            if i_level != self.num_resolutions - 1:
+                down.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res = curr_res // 2
+            self.down.append(down)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.mid.attn_1 = make_attn(block_in, attn_type=attn_type)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = _Conv2dOut(block_in, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1, padding=1)
+
+    def _pack(self, dev):
+        return {"conv_in": ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias, cin_pad=CIN_PAD, device=dev)}
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        for m in self.modules():
+            if isinstance(m, Packable):
+                m.invalidate_packed()
+        return r
+
+    def forward(self, x):
+        if x.device.type != "cuda":
+            raise ops._lib.VistaHipError("Encoder: images must be on the MI355X (vista_amd has no CPU path)")
+        n_img, _, H, W = x.shape
+        h = ops.nchw_to_tokens(x.float(), CIN_PAD)
+        h, _, _ = ops.conv3x3(h, self.packed()["conv_in"], n_img, H, W)
+        for i_level in range(self.num_resolutions):  # the reference's `hs` list only ever reads its last element
+            for i_block in range(self.num_res_blocks):
+                h = self.down[i_level].block[i_block](h, None, H, W)
+                if len(self.down[i_level].attn) > 0:
+                    h = self.down[i_level].attn[i_block](h, H, W)
+            if i_level != self.num_resolutions - 1:
+                h, H, W = self.down[i_level].downsample(h, H, W)
+        h = self.mid.block_1(h, None, H, W)
+        h = self.mid.attn_1(h, H, W)
+        h = self.mid.block_2(h, None, H, W)
+        h = ops.groupnorm(h, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps, silu=True)
+        return self.conv_out(h, H, W)
 
 
 class _Conv2dOut(ConvNd, Packable):

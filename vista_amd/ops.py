@@ -202,7 +202,7 @@ def linear_vt(x, pw, S, out=None):
 
 
 def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, rowvec=None, res1=None, res2=None, alpha=1.0,
-            beta=0.0):
+            beta=0.0, asym_pad=False):
     """3x3 conv, pad 1, over token-major x (n_img, H*W, Cin); `ups`=2 applies a nearest x2 upsample to the source
     on the fly (Upsample.forward, openaimodel.py:100-102); stride 2 = Downsample (openaimodel.py:136)."""
     _need(x, BF16, "x")
@@ -212,8 +212,9 @@ def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, row
     if pw.K != 9 * cin:
         raise ValueError(f"conv3x3: weight K {pw.K} != 9*{cin}")
     He, We = H * ups, W * ups
-    Hout = (He + 2 - 3) // stride + 1
-    Wout = (We + 2 - 3) // stride + 1
+    pad = 1 if asym_pad else 2  # asym_pad: F.pad(x, (0,1,0,1)) + conv pad 0 (VAE encoder Downsample, model.py:77-81)
+    Hout = (He + pad - 3) // stride + 1
+    Wout = (We + pad - 3) // stride + 1
     M = n_img * Hout * Wout
     if out is None:
         out = torch.empty((M, pw.N), dtype=F32 if out_f32 else BF16, device=x.device)
@@ -221,6 +222,7 @@ def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, row
     d.A, d.lda = _p(x), cin
     d.amode, d.epi = AMODE_CONV3X3, EPI_LINEAR
     d.H, d.Wd, d.Cin, d.Hout, d.Wout, d.stride, d.ups = H, W, cin, Hout, Wout, stride, ups
+    d.asym_pad = 1 if asym_pad else 0
     _fill_epilogue(d, pw, out, M, rowvec, Hout * Wout, res1, res2, alpha, beta)
     _gemm(d)
     return (out.view(n_img, Hout * Wout, pw.N) if out.is_contiguous() else out), Hout, Wout
@@ -488,6 +490,21 @@ def mask_replace(x, cond, mask):
     out = torch.empty_like(x)
     n = x.shape[0]
     check(_lib.load().vk_mask_replace(_p(x), _p(cond), _p(mask), _p(out), n, x.numel() // n, _stream()), "vk_mask_replace")
+    return out
+
+
+def gaussian_sample(moments, noise=None, scale=1.0):
+    """moments (n, 2C, h, w) f32 -> (n, C, h, w): (mean + exp(0.5*clamp(logvar)) * noise) * scale; noise None = mode."""
+    _need(moments, F32, "moments")
+    moments = moments.contiguous()
+    n, c2, h, w = moments.shape
+    if noise is not None:
+        _need(noise, F32, "noise")
+        noise = noise.contiguous()
+        if noise.shape != (n, c2 // 2, h, w):
+            raise ValueError("gaussian_sample: noise must be (n, C, h, w)")
+    out = torch.empty((n, c2 // 2, h, w), dtype=F32, device=moments.device)
+    check(_lib.load().vk_gaussian_sample(_p(moments), _p(noise), _p(out), n, c2 // 2, h * w, float(scale), _stream()), "vk_gaussian_sample")
     return out
 
 
