@@ -51,6 +51,17 @@ typedef struct VkGemmDesc {
  *   vwm/modules/diffusionmodules/video_model.py:38-52 (3x1x1 temporal conv), :148-157,176-182 (embedding MLPs), :189,438 (in/out conv) */
 int vk_gemm_bf16(const VkGemmDesc* d, void* stream);
 
+/* fp8 (OCP e4m3) variant of the DENSE GEMM for the UNet's Linear / 1x1 projections (BASELINE.json config 5: "fp8 1x1
+ * conv-as-GEMM path"; same reference call sites as vk_gemm_bf16's DENSE mode: attention.py:268-285,97-128, video_attention.py).
+ *   out = epilogue( a_scale[m] * w_scale[n] * sum_k Aq[m][k] * Wq[n][k] )
+ * d->A = fp8 activations [M][lda] (bytes), d->Wt = fp8 weights [ceil-tile(N)][d->K] with d->K = row stride, a multiple of 128,
+ * zero-filled past k_real; a_scale [M] per-row, w_scale [ceil-tile(N)] per-output-channel (GEGLU: packed row order);
+ * amode must be DENSE, epi LINEAR or GEGLU; the epilogue fields (bias, rowvec, res1/res2, alpha/beta, out_f32) as for bf16. */
+int vk_gemm_fp8(const VkGemmDesc* desc, const float* a_scale, const float* w_scale, int32_t k_real, void* stream);
+
+/* Per-row dynamic quantisation bf16 -> fp8 e4m3: scale[m] = max|x[m][:]| / 448, q = e4m3(x / scale). K % 8 == 0, K <= 5120. */
+int vk_quantize_rows_fp8(const void* x, void* q, float* scale, int32_t M, int32_t K, int64_t ldx, int64_t ldq, void* stream);
+
 /* ------------------------------------------------------------------ attention */
 /* Spatial self-attention, softmax(q k^T * scale) v per (image, head), head dim 64, no mask.
  * Replaces xformers.ops.memory_efficient_attention at vwm/modules/attention.py:400-407 for attn1 of

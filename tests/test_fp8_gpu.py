@@ -1,0 +1,113 @@
+"""fp8 (OCP e4m3) GEMM path of BASELINE config 5 on the MI355X.
+
+Two kinds of checks, with their tolerances stated:
+* kernel exactness: against an fp32 matmul of the DEQUANTISED operands (the very fp8 values the kernel multiplies) the only
+  difference is fp32 accumulation order and the bf16 output rounding -> same tolerance as the bf16 GEMM tests;
+* quantisation error (re-stated tolerance for config 5): per-row activation scales x per-channel weight scales, e4m3 has 3
+  mantissa bits (relative step 2^-3 at the top of a binade, 2^-4 mean) -> relative L2 error of one projection vs the
+  unquantised fp32 result <= 4.5e-2 on Gaussian data (measured ~3.6e-2 = sqrt(2) * 2.6e-2 for two quantised operands).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+def _ops():
+    from vista_amd import ops
+    return ops
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def deq(q_u8, scale):
+    return q_u8.cpu().view(torch.float8_e4m3fn).float() * scale.cpu()[:, None]
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).pow(2).sum() / b.pow(2).sum()).sqrt().item()
+
+
+@pytest.mark.parametrize("M,K", [(300, 320), (5, 64), (1000, 1280), (64, 5120), (257, 2432)])
+def test_quantize_rows(M, K):
+    ops = _ops()
+    x = (rnd(M, K) * torch.logspace(-2, 2, M)[:, None]).to(BF16).cuda()  # rows of very different magnitude
+    x[0] = 0                                                               # an all-zero row must not divide by zero
+    q, s = ops.quantize_rows_fp8(x)
+    xf = x.float().cpu()
+    want_s = (xf.abs().amax(1) / 448.0).masked_fill(xf.abs().amax(1) == 0, 1.0)
+    assert torch.allclose(s.cpu(), want_s, rtol=1e-6, atol=0)
+    want_q = (xf / want_s[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    got = q.cpu().view(torch.float8_e4m3fn)
+    # the kernel multiplies by 1/scale instead of dividing: a value on a rounding boundary may land one code apart
+    diff = (got.float() - want_q.float()).abs()
+    assert (diff > 0).float().mean().item() < 2e-3 and (diff <= want_q.float().abs() * 0.13 + 2 ** -9).all()
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(deq(q, s), xf) < 4e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (4608, 640, 1280), (1000, 960, 64), (128, 128, 128), (777, 1280, 2432), (260, 4, 320)])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4])
+def test_linear_fp8_exact_against_dequantised_operands(M, N, K, cfg):
+    ops = _ops()
+    x = rnd(M, K).to(BF16).cuda()
+    w = rnd(N, K, scale=K ** -0.5, seed=1)
+    b = rnd(N, seed=2)
+    pw = ops.pack_linear_fp8(w, b)
+    xq, xs = ops.quantize_rows_fp8(x)
+    r1 = rnd(M, N, seed=3).to(BF16).cuda()
+    ops.TILE_CFG = cfg
+    try:
+        out = ops.linear_fp8(xq, xs, pw, res1=r1, alpha=0.5)
+        out32 = ops.linear_fp8(xq, xs, pw, out_f32=True)
+    finally:
+        ops.TILE_CFG = 0
+    wd = pw.wt[:N, :K].cpu().view(torch.float8_e4m3fn).float() * pw.scale[:N].cpu()[:, None]
+    ref = deq(xq, xs) @ wd.t() + b
+    n_out = (N + 3) // 4 * 4
+    assert out32.shape == (M, n_out) and out.shape == (M, n_out)
+    err = (out32[:, :N].cpu() - ref).abs().max().item()
+    assert err <= 2e-3 * ref.pow(2).mean().sqrt().item() + 1e-5, f"fp8 GEMM f32 out: max err {err}"
+    ref2 = 0.5 * (ref + r1.float().cpu()[:, :N])
+    e2 = (out[:, :N].float().cpu() - ref2).abs()
+    assert (e2 <= 2e-2 * ref2.pow(2).mean().sqrt() + 1.6e-2 * ref2.abs()).all()
+    # and the re-stated config-5 tolerance against the UNQUANTISED projection
+    full = x.float().cpu() @ w.t() + b
+    assert rel_l2(out32[:, :N], full) <= 4.5e-2
+
+
+def test_geglu_fp8():
+    ops = _ops()
+    M, K, nout = 520, 320, 1280
+    x = rnd(M, K).to(BF16).cuda()
+    w = rnd(2 * nout, K, scale=K ** -0.5, seed=1)
+    b = rnd(2 * nout, seed=2)
+    pw = ops.pack_geglu_fp8(w, b)
+    xq, xs = ops.quantize_rows_fp8(x)
+    out = ops.linear_fp8(xq, xs, pw)
+    # dequantised reference in the ORIGINAL (value | gate) row order
+    idx = torch.arange(nout).reshape(-1, 32)
+    perm = torch.stack([idx, idx + nout], 1).reshape(-1)
+    wd = torch.empty(2 * nout, K)
+    wd[perm] = pw.wt[:2 * nout, :K].cpu().view(torch.float8_e4m3fn).float() * pw.scale[:2 * nout].cpu()[:, None]
+    h = deq(xq, xs) @ wd.t() + b
+    ref = h[:, :nout] * torch.nn.functional.gelu(h[:, nout:])
+    e = (out.float().cpu() - ref).abs()
+    assert out.shape == (M, nout) and (e <= 2e-2 * ref.pow(2).mean().sqrt() + 1.6e-2 * ref.abs()).all()
+
+
+def test_fp8_rejects_bad_arguments():
+    ops = _ops()
+    pw = ops.pack_linear_fp8(rnd(64, 64), None)
+    xq, xs = ops.quantize_rows_fp8(rnd(8, 64).to(BF16).cuda())
+    with pytest.raises(ValueError):
+        ops.linear_fp8(xq[:, :32], xs, pw)
+    with pytest.raises(TypeError):
+        ops.linear_fp8(xq.float(), xs, pw)
+    with pytest.raises(ValueError):
+        ops.pack_linear_fp8(rnd(64, 72), None)  # K % 16

@@ -31,6 +31,8 @@ class VkGemmDesc(C.Structure):
 # (tests/test_abi.py checks the header against this table and against the built library).
 SIGNATURES = {
     "vk_gemm_bf16": [C.POINTER(VkGemmDesc), _vp],
+    "vk_gemm_fp8": [C.POINTER(VkGemmDesc), _vp, _vp, _i32, _vp],
+    "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_temporal_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_softmax_rows_f32_bf16": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],

@@ -1,0 +1,170 @@
+// Pieces shared by the bf16 (gemm.hip) and fp8 (gemm_fp8.hip) implicit-GEMM kernels: operand-mode / epilogue enums and the fused
+// epilogue. Included inside each translation unit's own anonymous namespace scope.
+#pragma once
+#include "common.h"
+#include "vista_hip.h"
+
+namespace {
+
+enum { AMODE_DENSE = 0, AMODE_CONV3X3 = 1, AMODE_TEMPORAL3 = 2, AMODE_CONV3D = 3 };
+enum { EPI_LINEAR = 0, EPI_GEGLU = 1, EPI_TRANS = 2 };
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Fused epilogue shared by the GEMM kernels. Accumulator element r = 4*g + e of tile (fi,fj): X-row = 32*fi + 8*g + 4*lh + e,
+// Y-row = 32*fj + l31 (X = weights / Y = activations, swapped for EPI_TRANS). MW/NW = wave-tile extents along m / n.
+// Lane l31 of the lower half-wave (lh = 0) holds columns c..c+3 of accumulator quad g and lane l31 of the upper half the next
+// four, for the SAME output row. Swapping the upper half of quad g with the lower half of quad g+1 (v_permlane32_swap) leaves the
+// lower lane with 8 contiguous bf16 of quad g and the upper lane with 8 contiguous bf16 of quad g+1: one 16-byte store instead
+// of two 8-byte ones. The epilogue of these GEMMs is store-ISSUE bound (16-40 stores per lane), so halving the count matters most
+// where tiles are short (K = 320: 5 K-steps per tile).
+__device__ __forceinline__ uint4 widen_pair(uint2 qa, uint2 qb) {
+    const auto rx = __builtin_amdgcn_permlane32_swap(qa.x, qb.x, false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(qa.y, qb.y, false, false);
+    return make_uint4(rx[0], ry[0], rx[1], ry[1]);
+}
+
+template <int EPI, bool OUT_F32, int FX, int FY, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh) {
+    constexpr int MW = FM * 32, NW = FN * 32;
+    if (EPI == EPI_LINEAR) {
+        const float* __restrict__ bias = p.bias;
+        const float* __restrict__ rowvec = p.rowvec;
+        const uint16_t* __restrict__ res1 = (const uint16_t*)p.res1;
+        const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
+        // 16-byte stores need whole 16-column groups and 16-byte aligned rows (always true for the UNet's shapes)
+        const bool wide = !OUT_F32 && (p.N % 16 == 0) && (p.ldc % 8 == 0) && (((size_t)p.out & 15) == 0);
+#pragma unroll
+        for (int fj = 0; fj < FY; ++fj) {
+            const int m = m0 + wm * MW + fj * 32 + l31;
+            if (m >= p.M) continue;
+            const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+#pragma unroll
+            for (int fi = 0; fi < FX; ++fi) {
+                uint2 packed[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * NW + fi * 32 + 8 * g + 4 * lh;
+                    packed[g] = make_uint2(0, 0);
+                    if (n >= p.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
+                    if (bias) {
+                        const float4 b = *(const float4*)(bias + n);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (rv) {
+                        const float4 b = *(const float4*)(rv + n);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (res1) {
+                        const uint2 r = *(const uint2*)(res1 + (size_t)m * p.ld_res1 + n);
+                        v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                    if (res2) {
+                        const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
+                        v[0] += p.beta * bf16_lo(r.x); v[1] += p.beta * bf16_hi(r.x);
+                        v[2] += p.beta * bf16_lo(r.y); v[3] += p.beta * bf16_hi(r.y);
+                    }
+                    if (OUT_F32) {
+                        *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        packed[g].x = pack_bf16(v[0], v[1]);
+                        packed[g].y = pack_bf16(v[2], v[3]);
+                        if (!wide) *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + n) = packed[g];
+                    }
+                }
+                if (!OUT_F32 && wide) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int nb = n0 + wn * NW + fi * 32 + 16 * gp;  // both lanes of a row share the group's validity
+                        const uint4 w = widen_pair(packed[2 * gp], packed[2 * gp + 1]);
+                        if (nb < p.N) *(uint4*)((uint16_t*)p.out + (size_t)m * p.ldc + nb + 8 * lh) = w;
+                    }
+                }
+            }
+        }
+    } else if (EPI == EPI_GEGLU) {
+        // packed weight rows: every 64-row wave slice = [32 value rows | 32 gate rows]; fi=0 value, fi=1 gate
+        static_assert(EPI != EPI_GEGLU || FN == 2, "GEGLU packing assumes a 64-column wave tile");
+        const float* __restrict__ bias = p.bias;
+        const int nout = p.N >> 1;
+        const bool wide = (nout % 16 == 0) && (p.ldc % 8 == 0) && (((size_t)p.out & 15) == 0);
+#pragma unroll
+        for (int fj = 0; fj < FY; ++fj) {
+            const int m = m0 + wm * MW + fj * 32 + l31;
+            if (m >= p.M) continue;
+            uint2 packed[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int np = n0 + wn * 64 + 8 * g + 4 * lh;       // packed row of the value part
+                const int nc = (n0 >> 1) + wn * 32 + 8 * g + 4 * lh;  // output column
+                packed[g] = make_uint2(0, 0);
+                if (nc >= nout) continue;
+                float a[4], gt[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = acc[0][fj][4 * g + e]; gt[e] = acc[1][fj][4 * g + e]; }
+                if (bias) {
+                    const float4 ba = *(const float4*)(bias + np);
+                    const float4 bg = *(const float4*)(bias + np + 32);
+                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                }
+                packed[g].x = pack_bf16(a[0] * gelu_erf_f(gt[0]), a[1] * gelu_erf_f(gt[1]));
+                packed[g].y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
+                if (!wide) *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + nc) = packed[g];
+            }
+            if (wide) {
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    const int nb = (n0 >> 1) + wn * 32 + 16 * gp;
+                    const uint4 w = widen_pair(packed[2 * gp], packed[2 * gp + 1]);
+                    if (nb < nout) *(uint4*)((uint16_t*)p.out + (size_t)m * p.ldc + nb + 8 * lh) = w;
+                }
+            }
+        }
+    } else {  // EPI_TRANS: out[img][n][key], key = m % S contiguous
+        const bool wide = (p.S % 16 == 0) && (p.M % 16 == 0) && (((size_t)p.out & 15) == 0);
+#pragma unroll
+        for (int fj = 0; fj < FY; ++fj) {
+            const int n = n0 + wn * NW + fj * 32 + l31;
+            if (n >= p.N) continue;
+            const float bn = p.bias ? p.bias[n] : 0.f;  // the lane's output channel (VAE AttnBlock v projection carries a bias)
+#pragma unroll
+            for (int fi = 0; fi < FX; ++fi) {
+                uint2 packed[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    packed[g].x = pack_bf16(acc[fi][fj][4 * g + 0] + bn, acc[fi][fj][4 * g + 1] + bn);
+                    packed[g].y = pack_bf16(acc[fi][fj][4 * g + 2] + bn, acc[fi][fj][4 * g + 3] + bn);
+                    if (!wide) {
+                        const int m = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh;
+                        if (m >= p.M) continue;
+                        const int img = m / p.S;
+                        const int key = m - img * p.S;
+                        *(uint2*)((uint16_t*)p.out + ((size_t)img * p.N + n) * p.S + key) = packed[g];
+                    }
+                }
+                if (wide) {
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int mb = m0 + wm * MW + fi * 32 + 16 * gp;  // 16 consecutive keys of one image (S % 16 == 0)
+                        const uint4 w = widen_pair(packed[2 * gp], packed[2 * gp + 1]);
+                        if (mb < p.M) {
+                            const int img = mb / p.S;
+                            const int key = mb - img * p.S + 8 * lh;
+                            *(uint4*)((uint16_t*)p.out + ((size_t)img * p.N + n) * p.S + key) = w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace

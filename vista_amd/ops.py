@@ -286,6 +286,88 @@ def conv3d(x, pw, T, H, W, *, out=None, out_f32=False, res1=None, res2=None, alp
     return out.view(x.shape[0], H * W, -1) if out.dim() == 2 and out.is_contiguous() else out
 
 
+# ---------------------------------------------------------------------------------------------- fp8 GEMM (BASELINE config 5)
+FP8_MAX = 448.0  # OCP e4m3fn
+
+
+class PackedWeightF8:
+    """fp8 e4m3 [ceil-tile(N)][Kp] weight (Kp = ceil128(K), zero-filled) + f32 per-output-channel scale + f32 bias."""
+
+    __slots__ = ("wt", "scale", "bias", "N", "K", "Kp", "geglu")
+
+    def __init__(self, wt, scale, bias, N, K, Kp, geglu=False):
+        self.wt, self.scale, self.bias, self.N, self.K, self.Kp, self.geglu = wt, scale, bias, N, K, Kp, geglu
+
+
+def _finish_pack_fp8(w2d, bias, device, geglu=False):
+    N, K = w2d.shape
+    if K % 16:
+        raise ValueError("fp8 GEMM needs K % 16 == 0")
+    Kp = ceil_to(K, 128)
+    Np = max(ceil_to(N, 256), ceil_to(N, 320))
+    amax = w2d.abs().amax(dim=1).clamp_min(1e-12)
+    sc = (amax / FP8_MAX).float()
+    q = (w2d / sc[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    wt = torch.zeros((Np, Kp), dtype=torch.uint8, device=device)
+    wt[:N, :K] = q.view(torch.uint8).to(device)
+    scale = torch.ones((Np,), dtype=F32, device=device)
+    scale[:N] = sc.to(device)
+    b = None
+    if bias is not None:
+        b = torch.zeros((Np,), dtype=F32, device=device)
+        b[:N] = bias.to(device=device, dtype=F32)
+    return PackedWeightF8(wt, scale, b, ceil_to(N, 4), K, Kp, geglu)
+
+
+def pack_linear_fp8(weight, bias=None, device="cuda"):
+    """nn.Linear weight [N][K] -> per-output-channel-scaled fp8 (host-side, once per weight load)."""
+    return _finish_pack_fp8(weight.detach().reshape(weight.shape[0], -1).float().cpu(), None if bias is None else bias.detach().float().cpu(), device)
+
+
+def pack_geglu_fp8(weight, bias, device="cuda"):
+    """GEGLU.proj in the value/gate-interleaved row order of pack_geglu, quantised per packed row."""
+    w = weight.detach().float().cpu()
+    b = bias.detach().float().cpu()
+    nout = w.shape[0] // 2
+    if nout % 64:
+        raise ValueError("GEGLU width must be a multiple of 64")
+    idx = torch.arange(nout).reshape(-1, 32)
+    perm = torch.stack([idx, idx + nout], 1).reshape(-1)
+    return _finish_pack_fp8(w[perm], b[perm], device, geglu=True)
+
+
+def quantize_rows_fp8(x):
+    """x (..., K) bf16 (rows may be strided) -> (q uint8 (M, K) holding e4m3 bytes, scale f32 (M,)) with x ~= q * scale[:, None]."""
+    _need(x, BF16, "x")
+    x2, ldx = _rows2d(x, "x")
+    M, K = x2.shape
+    q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((M,), dtype=F32, device=x.device)
+    check(_lib.load().vk_quantize_rows_fp8(_p(x2), _p(q), _p(scale), M, K, ldx, K, _stream()), "vk_quantize_rows_fp8")
+    return q, scale
+
+
+def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0):
+    """out = alpha*((xq*a_scale) @ (Wq*w_scale)^T + bias + rowvec + res1) + beta*res2, fp8 x fp8 -> f32 accumulate."""
+    if xq.dtype != torch.uint8 or xq.dim() != 2 or xq.stride(1) != 1:
+        raise TypeError("linear_fp8: xq must be a (M, K) uint8 tensor of e4m3 bytes")
+    M, K = xq.shape
+    if K != pw.K:
+        raise ValueError(f"linear_fp8: K mismatch {K} vs {pw.K}")
+    nout = pw.N // 2 if pw.geglu else pw.N
+    if out is None:
+        out = torch.empty((M, nout), dtype=F32 if (out_f32 and not pw.geglu) else BF16, device=xq.device)
+    d = VkGemmDesc()
+    d.A, d.lda = _p(xq), xq.stride(0)
+    d.amode = AMODE_DENSE
+    d.epi = EPI_GEGLU if pw.geglu else EPI_LINEAR
+    _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta)
+    d.K = pw.Kp
+    d.tile_cfg = TILE_CFG & 7
+    check(_lib.load().vk_gemm_fp8(C.byref(d), _p(a_scale), _p(pw.scale), K, _stream()), "vk_gemm_fp8")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- attention
 PROFILE_ATTN = None  # bench.py sets this to a list: (S, n_img*heads, start_event, end_event) per launch, on the launch stream
 
