@@ -82,7 +82,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shard", choices=["hybrid", "frames"], default="hybrid")
     ap.add_argument("--cpu-sample", type=str, default="16x32")
+    ap.add_argument("--fp8-ff", action="store_true",
+                    help="BASELINE config 5 experiment, NOT the headline: FeedForward GEMMs in fp8 e4m3 (reported dtype says so)")
     args = ap.parse_args()
+    if args.fp8_ff:
+        from vista_amd.modules import attention as _att
+        _att.FP8["feedforward"] = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,7 +177,7 @@ def main():
                     "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop}
     res = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16 + fp8(e4m3) FeedForward GEMMs [config 5 experiment]" if args.fp8_ff else "bf16",
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (DRY RUN: gloo host-staged transport, ranks share one GPU -- not a result)",
         "config": {"workload": (f"{world}xMI355X" + ((" CFG-split x2 x" if shard.cfg_half is not None else "") + " frame-sharded " +
                                                      "/".join(str(c) for c in shard.t_counts) if shard else "") +

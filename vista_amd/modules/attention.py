@@ -13,6 +13,8 @@ activations ((n_img*S, C), C contiguous) and runs entirely on the HIP kernels of
                                              influence the result and are kept only for state-dict compatibility.
       x += FF(norm3(x))                      LN -> GEGLU GEMM (value*gelu(gate) fused in the epilogue) -> out GEMM(+res)
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -54,6 +56,11 @@ class GEGLU(nn.Module):
         self.proj = Linear(dim_in, dim_out * 2)
 
 
+# BASELINE config 5 opt-in (off by default; the headline path is bf16): run the FeedForward GEMMs -- GEGLU in-projection and
+# out-projection, 32 % of the UNet's FLOPs -- in fp8 e4m3 with per-token activation scales and per-channel weight scales.
+FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1"}
+
+
 class FeedForward(nn.Module, Packable):
     """attention.py:95-128 (glu=True on this path). net = [GEGLU, Dropout, Linear] -> keys net.0.proj.*, net.2.*"""
 
@@ -68,13 +75,25 @@ class FeedForward(nn.Module, Packable):
             zero_module(self.net[-1])
 
     def _pack(self, dev):
-        return {"in": ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev),
-                "out": ops.pack_linear(self.net[2].weight, self.net[2].bias, dev)}
+        pk = {"in": ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev),
+              "out": ops.pack_linear(self.net[2].weight, self.net[2].bias, dev)}
+        if FP8["feedforward"]:
+            pk["in8"] = ops.pack_geglu_fp8(self.net[0].proj.weight, self.net[0].proj.bias, dev)
+            pk["out8"] = ops.pack_linear_fp8(self.net[2].weight, self.net[2].bias, dev)
+        return pk
 
     def forward(self, y, **epilogue):
         """y: LN output (M, dim). Returns net(y) fused with the residual / blend epilogue given by the caller."""
         pk = self.packed()
-        return ops.linear(ops.linear(y, pk["in"]), pk["out"], **epilogue)
+        if not FP8["feedforward"]:
+            return ops.linear(ops.linear(y, pk["in"]), pk["out"], **epilogue)
+        if "in8" not in pk:  # the switch was flipped after the bf16 pack was built
+            self.invalidate_packed()
+            pk = self.packed()
+        yq, ys = ops.quantize_rows_fp8(y)
+        h = ops.linear_fp8(yq, ys, pk["in8"])
+        hq, hs = ops.quantize_rows_fp8(h)
+        return ops.linear_fp8(hq, hs, pk["out8"], **epilogue)
 
 
 class MemoryEfficientCrossAttention(nn.Module, Packable):
