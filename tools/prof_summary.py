@@ -35,6 +35,17 @@ def main():
     for k, (c, t, p) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{k:62s} {c:7d} {t/1e3:10.2f} {t/c:10.2f} {p:6.2f}")
     print(f"{'TOTAL':62s} {sum(v[0] for v in agg.values()):7d} {sum(v[1] for v in agg.values())/1e3:10.2f}")
+    # the roofline kernel, split by launch geometry (grid x = workgroups: level 0 of the UNet is the largest grid), so that its
+    # average duration can be compared with bench.py's `roofline.avg_ms` (which times only the level-0 launches)
+    try:
+        rows = list(db.execute("select name, grid_x, workgroup_x, count(*), avg(duration), sum(duration) from kernels "
+                               "where name like '%attn_spatial_kernel%' group by name, grid_x, workgroup_x order by sum(duration) desc"))
+    except sqlite3.Error:
+        rows = []
+    if rows:
+        print("\nattn_spatial_kernel by launch geometry (grid_x = threads):")
+        for n, gx, wx, c, avg, tot in rows:
+            print(f"  {short(n):28s} grid_x {gx:9d} wg {wx:4d}  calls {c:4d}  avg_us {avg/1e3:9.2f}  total_ms {tot/1e6:8.2f}")
 
 
 if __name__ == "__main__":
