@@ -97,7 +97,7 @@ def test_sharded_sampler_matches_golden():
     assert r <= 4e-2 and torch.equal(outs[0][0], w["cond_frame"][0])
 
 
-@pytest.mark.parametrize("world,mode", [(2, "hybrid"), (4, "hybrid"), (6, "hybrid"), (3, "hybrid")])
+@pytest.mark.parametrize("world,mode", [(2, "hybrid"), (4, "hybrid"), (6, "hybrid"), (3, "hybrid"), (8, "hybrid")])
 def test_hybrid_cfg_x_frame_sampler_matches_golden(world, mode):
     """CFG x frame hybrid (make_shard): world=2 -> pure CFG split, 4 -> 2x2, 6 -> 2x3; odd world falls back to frame sharding."""
     from tests.test_model_gpu import _sampler, tiny_unet
@@ -138,3 +138,49 @@ def test_hybrid_cfg_x_frame_sampler_matches_golden(world, mode):
     r = rel_l2(outs[0], g["triangle"])
     print(f"[parity] hybrid world={world}: rel-L2 {r:.3e}")
     assert r <= 4e-2 and torch.equal(outs[0][0], w["cond_frame"][0])
+
+
+def test_eight_ranks_25_frames_hybrid_and_frames_layouts_vs_config1_golden():
+    """The 8-GPU layouts of the bench in miniature, with thread ranks on one GPU: 25 frames, 10 EDM steps, VanillaCFG 2.5
+    (config1_tiny golden from the real reference sampler). hybrid = 2 CFG halves x (7/6/6/6); frames = BASELINE config 3's 4/3/3/3/3/3/3/3."""
+    from tests.test_model_gpu import _sampler, tiny_unet
+    from vista_amd import synth
+    from vista_amd.modules.diffusionmodules.denoiser import Denoiser
+    from vista_amd.modules.diffusionmodules.sampling import FusedDenoiser
+    from vista_amd.modules.diffusionmodules.wrappers import OpenAIWrapper
+    from vista_amd.parallel import ThreadGroups, make_shard
+    g = torch.load(os.path.join(GOLD, "config1_tiny.pt"))
+    net, _ = tiny_unet()
+    T, H, W, world = g["T"], g["H"], g["W"], 8
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1)
+    den = Denoiser(scaling_config={"target": "vwm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
+    fused = FusedDenoiser(den, OpenAIWrapper(net))
+    cfg = {"target": "vwm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 2.5}}
+    for mode, counts in (("hybrid", [7, 6, 6, 6]), ("frames", [4, 3, 3, 3, 3, 3, 3, 3])):
+        groups = ThreadGroups()
+        outs, errs, seen = [None] * world, [], [None] * world
+
+        def run(rank):
+            try:
+                torch.cuda.set_device(0)
+                s = _sampler(cfg, steps=g["steps"])
+                s.shard = make_shard(T, world, rank, mode=mode, make_group=groups.make(rank))
+                seen[rank] = list(s.shard.t_counts)
+                cu = lambda d: {k: v.clone().cuda() for k, v in d.items()}  # noqa: E731
+                outs[rank] = s(fused, w["noise"].clone().cuda(), cond=cu(w["c"]), uc=cu(w["uc"]), cond_frame=w["cond_frame"].cuda(),
+                               cond_mask=w["cond_mask"].cuda()).cpu()
+            except Exception:  # noqa: BLE001
+                import traceback
+                errs.append(traceback.format_exc())
+                groups.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs[0]
+        assert all(c == counts for c in seen), seen
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        r = rel_l2(outs[0], g["out"].float())
+        print(f"[parity] 8 ranks, 25 frames, 10 steps, {mode}: rel-L2 {r:.3e}")
+        assert r <= 4e-2
