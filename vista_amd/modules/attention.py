@@ -35,8 +35,14 @@ class Packable:
     _pk = None
     _pk_dev = None
 
+    _pk_param = None
+
     def packed(self):
-        dev = next(self.parameters()).device
+        p = self._pk_param
+        if p is None:  # one Parameter kept as the device probe: .cuda()/.to() swap its .data in place, so its .device stays current
+            p = next(self.parameters())
+            object.__setattr__(self, "_pk_param", p)  # plain attribute: nn.Module.__setattr__ would register it as a parameter
+        dev = p.device
         if dev.type != "cuda":
             raise ops._lib.VistaHipError(f"{self.__class__.__name__}: parameters are on {dev}; move the model to the MI355X "
                                          "(.cuda()) -- vista_amd has no CPU path")

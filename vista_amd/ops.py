@@ -19,7 +19,9 @@ F32 = torch.float32
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw hipStream_t of torch's current stream on the current device; the C-level getters cost ~1 us against ~9 us for
+    # torch.cuda.current_stream() (1500 launches per step go through here)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _p(t):

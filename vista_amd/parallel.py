@@ -302,8 +302,11 @@ class FrameShard:
 
     def take_local_rows(self, full):
         """Rows of a (B*T, ...) replicated tensor that belong to this rank's images, in local order."""
-        idx = torch.tensor(self.local_image_ids(), device=full.device)
-        return full.index_select(0, idx)
+        key = str(full.device)
+        cache = self.__dict__.setdefault("_local_rows_idx", {})
+        if key not in cache:  # built once: torch.tensor(list, device=cuda) is a blocking host->device copy (6 ms mid-step)
+            cache[key] = torch.tensor(self.local_image_ids(), device=full.device)
+        return full.index_select(0, cache[key])
 
     def exchange_cfg_halves(self, net_out_half):
         """Hybrid mode: (t_local, S, C) output of this rank's CFG half -> (2*t_local, S, C) [uncond; cond] on both partners."""
