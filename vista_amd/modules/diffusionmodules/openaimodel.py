@@ -134,7 +134,14 @@ class ResBlock(TimestepBlock, Packable):
         gn1, gn2 = self.in_layers[0], self.out_layers[0]
         fpg = 1 if self.dims == 2 else T
         # (n_img, Cout): `emb_layers(emb)[..., None, None]`; skip_t_emb adds zeros (openaimodel.py:268-269)
-        emb_out = None if self.emb_layers is None else ops.linear(emb_silu, pk["emb"], out_f32=True)
+        src = getattr(self, "_emb_src", None)  # (thread-local table, column offset, width) when a VideoUNet owns this block
+        table = getattr(src[0], "table", None) if src is not None else None
+        if self.emb_layers is None:
+            emb_out = None
+        elif table is not None and table.shape[0] == n_img:
+            emb_out = table[:, src[1]:src[1] + src[2]]  # the UNet already projected silu(emb) for every block in one GEMM
+        else:
+            emb_out = ops.linear(emb_silu, pk["emb"], out_f32=True)
 
         def gnorm(t, gn):
             if shard is None or self.dims == 2:

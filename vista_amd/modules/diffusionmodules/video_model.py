@@ -7,6 +7,8 @@ boundary tensors are converted by HIP layout kernels at entry and exit.
 """
 from typing import List, Optional, Union
 
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -193,6 +195,17 @@ class VideoUNet(nn.Module, Packable):
 
         self.out = nn.Sequential(normalization(ch), SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
         self._frame_idx_cache = {}
+        # Every ResBlock (spatial and time_stack) projects the SAME silu(emb) through its own emb_layers Linear: 44 launches of a
+        # 7..50-row GEMM per forward. forward_tokens runs them as ONE GEMM over the row-concatenated weights and hands each block
+        # its column slice through this thread-local table (thread-local: the multi-rank tests drive one model from several threads).
+        self._emb_tls = threading.local()
+        off = 0
+        self._emb_blocks = []
+        for m in self.modules():
+            if isinstance(m, ResBlock) and m.emb_layers is not None:
+                object.__setattr__(m, "_emb_src", (self._emb_tls, off, m.out_channels))
+                self._emb_blocks.append(m)
+                off += m.out_channels
 
     # ---- weights ----
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -208,7 +221,10 @@ class VideoUNet(nn.Module, Packable):
     def _pack(self, dev):
         def mlp(seq):
             return (ops.pack_linear(seq[0].weight, seq[0].bias, dev), ops.pack_linear(seq[2].weight, seq[2].bias, dev))
-        return {"time_embed": mlp(self.time_embed), "cond": mlp(self.cond_time_stack_embed), "label": mlp(self.label_emb[0]),
+        emb_w = torch.cat([m.emb_layers[1].weight.detach().float() for m in self._emb_blocks], 0)
+        emb_b = torch.cat([m.emb_layers[1].bias.detach().float() for m in self._emb_blocks], 0)
+        return {"emb_cat": ops.pack_linear(emb_w, emb_b, dev),
+                "time_embed": mlp(self.time_embed), "cond": mlp(self.cond_time_stack_embed), "label": mlp(self.label_emb[0]),
                 "out": ops.pack_conv3x3(self.out[2].weight, self.out[2].bias, device=dev)}
 
     def _frame_idx(self, n_img, T, device):
@@ -268,15 +284,19 @@ class VideoUNet(nn.Module, Packable):
             ctx = shard.take_local_rows(ctx)
         kw = dict(frame_idx=frame_idx, num_frames=T, shard=shard, full=full)
 
-        hs = []
-        h = tokens
-        for module in self.input_blocks:
-            h, H, W = module(h, emb_silu, context=ctx, H=H, W=W, **kw)
-            hs.append(h)
-        h, H, W = self.middle_block(h, emb_silu, context=ctx, H=H, W=W, **kw)
-        for module in self.output_blocks:
-            h = ops.concat_channels(h, hs.pop())
-            h, H, W = module(h, emb_silu, context=ctx, H=H, W=W, **kw)
+        self._emb_tls.table = ops.linear(emb_silu, pk["emb_cat"], out_f32=True)  # all emb_layers projections of this forward
+        try:
+            hs = []
+            h = tokens
+            for module in self.input_blocks:
+                h, H, W = module(h, emb_silu, context=ctx, H=H, W=W, **kw)
+                hs.append(h)
+            h, H, W = self.middle_block(h, emb_silu, context=ctx, H=H, W=W, **kw)
+            for module in self.output_blocks:
+                h = ops.concat_channels(h, hs.pop())
+                h, H, W = module(h, emb_silu, context=ctx, H=H, W=W, **kw)
+        finally:
+            self._emb_tls.table = None
         gn = self.out[0]
         h = ops.groupnorm(h, gn.weight, gn.bias, gn.eps, silu=True)
         out, _, _ = ops.conv3x3(h, pk["out"], tokens.shape[0], H, W, out_f32=True)
