@@ -42,7 +42,8 @@ def close(out, ref, name, rtol=1.6e-2, arel=2e-2):
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (50, 1280, 768), (128, 128, 64), (1000, 4, 576), (257, 960, 2432), (4608, 640, 1280)])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (50, 1280, 768), (128, 128, 64), (1000, 4, 576), (257, 960, 2432), (4608, 640, 1280),
+                                   (66597, 320, 64), (33300, 640, 128)])  # more tiles than CUs, ragged M
 def test_linear_plain(M, N, K):
     ops = _ops()
     x = rnd(M, K)
@@ -126,7 +127,8 @@ def _nchw2tok(x):
 
 @pytest.mark.parametrize("n,H,W,Cin,Cout,stride,ups", [
     (2, 9, 16, 64, 320, 1, 1), (3, 18, 32, 320, 320, 1, 1), (2, 18, 32, 128, 64, 2, 1), (2, 9, 16, 192, 128, 1, 2),
-    (1, 72, 128, 64, 4, 1, 1), (2, 7, 5, 64, 64, 1, 1), (2, 8, 6, 64, 64, 2, 1)])
+    (1, 72, 128, 64, 4, 1, 1), (2, 7, 5, 64, 64, 1, 1), (2, 8, 6, 64, 64, 2, 1),
+    (8, 96, 88, 64, 320, 1, 1)])  # 264 row tiles: more than one round of workgroups on 256 CUs
 def test_conv3x3(n, H, W, Cin, Cout, stride, ups):
     ops = _ops()
     x = rnd(n, H * W, Cin)
