@@ -190,7 +190,8 @@ def _sdpa(q, k, v):
     return torch.softmax(s, -1) @ v.float()
 
 
-@pytest.mark.parametrize("n_img,heads,S", [(2, 5, 144), (1, 2, 576), (3, 1, 64), (1, 5, 2304), (2, 3, 200), (1, 1, 9216)])
+@pytest.mark.parametrize("n_img,heads,S", [(2, 5, 144), (1, 2, 576), (3, 1, 64), (1, 5, 2304), (2, 3, 200), (1, 1, 9216),
+                                           (1, 2, 2048), (2, 1, 2120), (1, 1, 2056), (1, 3, 4104)])  # >= 2048: ragged last q-block / key tile, odd and even tile counts
 def test_attn_spatial(n_img, heads, S):
     ops = _ops()
     Cc = heads * 64
