@@ -172,6 +172,10 @@ int vk_scale_rows(const float* x, const float* s, float* out, int32_t n_img, int
 int vk_gaussian_sample(const float* moments, const float* noise, float* out, int32_t n_img, int32_t C, int32_t hw, float scale,
                        void* stream);
 
+/* Reward estimation (reward_utils.py:329-335): out[0] = sum_i sum_e (x[e][i] - mean_e)^2 / (E - 1) over an ensemble x[E][n] of f32
+ * latents, reduced in a fixed order (f64 partials; partial_ws: 512 doubles). The caller forms exp(-out/n). */
+int vk_ensemble_variance_sum(const float* x, double* out, double* partial_ws, int32_t E, int64_t n, void* stream);
+
 /* library info */
 int vk_abi_version(void);
 

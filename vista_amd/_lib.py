@@ -55,6 +55,7 @@ SIGNATURES = {
     "vk_mask_replace": [_vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "vk_scale_rows": [_vp, _vp, _vp, _i32, _i32, _vp],
     "vk_gaussian_sample": [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp],
+    "vk_ensemble_variance_sum": [_vp, _vp, _vp, _i32, _i64, _vp],
     "vk_abi_version": [],
 }
 

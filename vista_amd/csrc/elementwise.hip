@@ -204,6 +204,35 @@ __global__ void gaussian_sample_kernel(const float* __restrict__ mom, const floa
     }
 }
 
+// sum over i of  sum_e (x[e][i] - mean_e x[.][i])^2 / (E - 1): per-block partials in a fixed order, then one block adds them.
+__global__ __launch_bounds__(256) void ens_var_partial_kernel(const float* __restrict__ x, double* __restrict__ partial, int E, long long n) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float mean = 0.f;
+        for (int e = 0; e < E; ++e) mean += x[(size_t)e * n + i];
+        mean /= (float)E;
+        float d2 = 0.f;
+        for (int e = 0; e < E; ++e) {
+            const float d = x[(size_t)e * n + i] - mean;
+            d2 = fmaf(d, d, d2);
+        }
+        acc += (double)(d2 / (float)(E - 1));
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void ens_var_final_kernel(const double* __restrict__ partial, double* __restrict__ out, int nblk) {
+    double a = 0.0;
+    for (int i = 0; i < nblk; ++i) a += partial[i];
+    out[0] = a;
+}
+
 }  // namespace
 
 #define EW_LAUNCH(kernel, count, ...)                                                                          \
@@ -278,5 +307,14 @@ extern "C" int vk_gaussian_sample(const float* moments, const float* noise, floa
                                   void* stream) {
     if (!moments || !out || n_img <= 0 || C <= 0 || hw <= 0) return VK_EINVAL;
     EW_LAUNCH(gaussian_sample_kernel, (long long)n_img * C * hw, moments, noise, out, n_img, C * hw, scale);
+}
+extern "C" int vk_ensemble_variance_sum(const float* x, double* out, double* partial_ws, int32_t E, int64_t n, void* stream) {
+    if (!x || !out || !partial_ws || E < 2 || n <= 0) return VK_EINVAL;
+    const int nblk = 512;
+    hipLaunchKernelGGL(ens_var_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, partial_ws, E, (long long)n);
+    VK_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ens_var_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)partial_ws, out, nblk);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
 }
 extern "C" int vk_abi_version(void) { return 1; }

@@ -592,6 +592,18 @@ def gaussian_sample(moments, noise=None, scale=1.0):
     return out
 
 
+def ensemble_variance_sum(x):
+    """x (E, ...) f32 -> python float: sum over elements of the unbiased variance across the E ensemble members."""
+    _need(x, F32, "x")
+    x = x.contiguous()
+    E = x.shape[0]
+    n = x.numel() // E
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    ws = torch.empty(512, dtype=torch.float64, device=x.device)
+    check(_lib.load().vk_ensemble_variance_sum(_p(x), _p(out), _p(ws), E, n, _stream()), "vk_ensemble_variance_sum")
+    return float(out.item())
+
+
 def scale_rows(x, s):
     x, s = _c(x, s)
     out = torch.empty_like(x)
