@@ -31,7 +31,7 @@ namespace {
 __device__ uint4 g_zero16;  // source of the zero fill for out-of-image conv taps on the LDS-DMA path (zero-initialised)
 
 template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_kernel(const VkGemmDesc p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_kernel(const VkGemmDesc p) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;              // threads
     constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 x 16-B chunks per 128-B row)
@@ -302,7 +302,12 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
     if constexpr (EPI != EPI_GEGLU && AMODE != AMODE_CONV3D) {
         if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 5>(d, stream);
     }
-    if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 2, 4, 4, 2>(d, stream);
+    // 256x256 runs as SIXTEEN waves (4 per SIMD, 64x64 wave tiles, <= 128 VGPRs): same bytes per FLOP as the 8-wave layout, but twice
+    // the waves to cover LDS-read latency, DMA issue and the per-K-step barrier (+5-10 % on GEGLU and the N % 320 != 0 projections).
+    if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 2>(d, stream);
+    if constexpr (EPI != EPI_GEGLU) {
+        if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 1>(d, stream);  // 256x128, sixteen 64x32 wave tiles
+    }
     if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 2>(d, stream);
     return launch_cfg<AMODE, EPI, OUT_F32, 2, 2, 2, 2>(d, stream);
 }
