@@ -35,11 +35,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;              // threads
     constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 x 16-B chunks per 128-B row)
-    constexpr int AP = BM / RPP, WP = BN / RPP;   // staging passes for the A / W tiles
+    constexpr int AP = BM / RPP, WP = (BN + RPP - 1) / RPP;   // staging passes for the A / W tiles (the last W pass may be partial)
     constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
     constexpr bool TR = (EPI == EPI_TRANS);
     constexpr int FX = TR ? FM : FN, FY = TR ? FN : FM;  // MFMA row-operand / column-operand fragments per wave
-    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+    static_assert(BM % RPP == 0 && BN % 8 == 0, "A rows must be a multiple of the staging pass, W rows of a wave's 8-row slice");
+    constexpr bool FRAG_DB = (NT <= 512) || (FX * FY <= 4);  // 16 waves x 32x160 wave tiles: no registers for double-buffered fragments
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x;
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         char* sW = sA + A_BYTES;
 #pragma unroll
         for (int i = 0; i < WP; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wptr[i] + k0), (lptr_t)(sW + i * RPP * 128), 16, 0, 0);
+            if (RPP * (i + 1) <= BN || RPP * i + 8 * wave_u < BN)  // wave-uniform: waves past the tile's last row skip the partial pass
+                __builtin_amdgcn_global_load_lds((gptr_t)(wptr[i] + k0), (lptr_t)(sW + i * RPP * 128), 16, 0, 0);
         if (AMODE == AMODE_DENSE) {
             if (p.tile_cfg & 32) {  // set by launch_cfg: non-temporal policy for an activation stream with little reuse
 #pragma unroll
@@ -210,6 +212,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     };
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
+        if constexpr (!FRAG_DB) {  // four waves per SIMD cover the LDS latency instead of a second fragment buffer
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8_t xs[FX], ys[FY];
+                load_frags(sb, ks, xs, ys);
+                mma(xs, ys);
+            }
+            return;
+        }
         bf16x8_t xa[FX], ya[FY], xb[FX], yb[FY];
         // sched_barrier(0) pins the phase order; without it hipcc sinks every read next to its first use again
         load_frags(sb, 0, xa, ya);
@@ -300,7 +311,9 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
         else cfg = 1;
     }
     if constexpr (EPI != EPI_GEGLU && AMODE != AMODE_CONV3D) {
-        if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 5>(d, stream);
+        // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
+        // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
+        if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream);
     }
     // 256x256 runs as SIXTEEN waves (4 per SIMD, 64x64 wave tiles, <= 128 VGPRs): same bytes per FLOP as the 8-wave layout, but twice
     // the waves to cover LDS-read latency, DMA issue and the per-K-step barrier (+5-10 % on GEGLU and the N % 320 != 0 projections).
