@@ -322,7 +322,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
         if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 1>(d, stream);  // 256x128, sixteen 64x32 wave tiles
     }
     if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 2>(d, stream);
-    return launch_cfg<AMODE, EPI, OUT_F32, 2, 2, 2, 2>(d, stream);
+    return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 1, 2>(d, stream);  // 128x128 as eight 32x64 wave tiles, two workgroups per CU
 }
 
 }  // namespace
