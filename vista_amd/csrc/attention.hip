@@ -18,6 +18,8 @@
 //   vwm/modules/video_attention.py:116-127, attention.py:384-399): one wave per (batch, pixel, head); Q/K
 //   fragments are loaded straight from HBM (rows are frames, stride S*ld), V goes through a 4 KiB wave-private
 //   LDS tile and is gathered in the accumulator's key order. HBM-bound by construction (12.5 FLOP/B).
+#include <stdlib.h>
+
 #include "common.h"
 #include "vista_hip.h"
 
@@ -48,7 +50,7 @@ template <int NW>  // waves per workgroup: NW*32 query rows share each 64-key K 
 __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                   const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
                                                                   int n_img, int heads, int S, int ldq, int ldk, int ldo,
-                                                                  float scale_log2) {
+                                                                  float scale_log2, float rescale_thr) {
     constexpr int QB = NW * 32;   // query rows per workgroup
     constexpr int GPW = 8 / NW;   // 8-row DMA groups of each tile handled per wave
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // per stage: K tile 8 KiB | V^T tile 8 KiB
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_kernel(const uint16_t
         // grew less keeps its old base and its probabilities of this tile are at most 2^THR instead of 1 -- the bf16 P and the fp32
         // accumulators keep their RELATIVE precision, and the final division by l removes the common factor. Without the
         // threshold about half of the 144 tiles of a 9216-key row block take this branch (P(new max) ~ 32 rows / tile index).
-        if (__any(mx > m_run + RESCALE_THR)) {  // wave-uniform
+        if (__any(mx > m_run + rescale_thr)) {  // wave-uniform
             const float m_new = fmaxf(m_run, mx);
             const float alpha = fast_exp2(m_run - m_new);
             m_run = m_new;
@@ -423,6 +425,7 @@ extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt
     if ((S % 8) != 0 || (ldq % 8) != 0 || (ldk % 8) != 0 || (ldo % 4) != 0) return VK_EINVAL;
     // long sequences: 256 query rows (8 waves) per workgroup halve the K/V^T stream per FLOP; short ones keep 128 rows so the
     // ragged last q-block wastes less (S = 144, 576 at the deep levels)
+    static const float thr = [] { const char* e = getenv("VISTA_ATTN_RESCALE_THR"); return e ? (float)atof(e) : RESCALE_THR; }();  // tuning / A-B
     const bool big = S >= 2048;
     const int qb_rows = big ? 256 : 128;
     const int nqb = (S + qb_rows - 1) / qb_rows;
@@ -430,10 +433,10 @@ extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt
     if (nblk > 0x7fffffffLL) return VK_EINVAL;
     if (big)
         hipLaunchKernelGGL(attn_spatial_kernel<8>, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream_, (const uint16_t*)q,
-                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E);
+                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr);
     else
         hipLaunchKernelGGL(attn_spatial_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)q,
-                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E);
+                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
