@@ -41,6 +41,8 @@ typedef struct VkGemmDesc {
     const void* halo_prev; /* TEMPORAL3, frame-sharded runs: bf16 [clips][S][Cin] frame preceding / following the local frame range   */
     const void* halo_next; /* (from the neighbour rank); NULL = the conv's zero padding at the window ends                               */
     void* dbg;           /* tuning only: if non-NULL, per-wave phase timers (u64 x4 per wave, 16 waves per sampled block)  */
+    void* splitk_ws;     /* optional fp32 workspace for split-K of small-M, deep-K LINEAR problems (NULL = never split); must not be  */
+    int64_t splitk_ws_bytes; /* shared by GEMMs in flight on different streams. A split needs slices * M * N * 4 bytes.              */
     int32_t asym_pad;    /* CONV3X3: 0 = zero padding 1 on all sides; 1 = padding (0,1,0,1) = bottom/right only, the VAE encoder's
                             Downsample (vwm/modules/diffusionmodules/model.py:77-81: F.pad(x, (0,1,0,1)) then conv stride 2 pad 0)  */
 } VkGemmDesc;

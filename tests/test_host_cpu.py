@@ -38,7 +38,7 @@ def test_gemm_desc_layout_matches_header():
         decl = decl.strip()
         if not decl or decl.startswith("typedef"):
             continue
-        decl = re.sub(r"^(const\s+)?(void|float|int32_t)\s*\*?", "", decl).strip()
+        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl).strip()
         names += [n.strip().lstrip("*") for n in decl.split(",")]
     assert names == [f[0] for f in _lib.VkGemmDesc._fields_], names
 

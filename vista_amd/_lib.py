@@ -23,7 +23,7 @@ class VkGemmDesc(C.Structure):
         ("alpha", _f32), ("beta", _f32),
         ("amode", _i32), ("epi", _i32), ("out_f32", _i32),
         ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32),
-        ("T", _i32), ("S", _i32), ("tile_cfg", _i32), ("halo_prev", _vp), ("halo_next", _vp), ("dbg", _vp), ("asym_pad", _i32),
+        ("T", _i32), ("S", _i32), ("tile_cfg", _i32), ("halo_prev", _vp), ("halo_next", _vp), ("dbg", _vp), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("asym_pad", _i32),
     ]
 
 

@@ -31,7 +31,7 @@ namespace {
 __device__ uint4 g_zero16;  // source of the zero fill for out-of-image conv taps on the LDS-DMA path (zero-initialised)
 
 template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_kernel(const VkGemmDesc p) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_kernel(const VkGemmDesc p, const int ksplit) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;              // threads
     constexpr int RPP = NT / 8;                   // tile rows staged per pass (8 x 16-B chunks per 128-B row)
@@ -51,7 +51,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
 
     const int tilesN = (p.N + BN - 1) / BN;
     const int tilesM = (p.M + BM - 1) / BM;
-    const int logical = xcd_remap(blockIdx.x, tilesM * tilesN);
+    // split-K (small-M problems): workgroup = (K slice, tile), K slice as the slow index so neighbours still share weight tiles
+    const int ntiles = tilesM * tilesN;
+    const int lin = xcd_remap(blockIdx.x, ntiles * ksplit);
+    const int kslice = lin / ntiles, logical = lin - kslice * ntiles;
     const int tn = logical % tilesN, tm = logical / tilesN;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -106,7 +109,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         }
     }
 
-    int tap = 0, c0 = 0;  // (tap, channel offset) of the next K-step to stage, for the conv loaders
+    const int nk_all = p.K / BK;
+    const int kt0 = (int)((long long)kslice * nk_all / ksplit), kt1 = (int)((long long)(kslice + 1) * nk_all / ksplit);
+    // (tap, channel offset) of the next K-step to stage, for the conv loaders: starts at this workgroup's first K-step
+    int tap = (AMODE == AMODE_DENSE) ? 0 : (kt0 * BK) / p.Cin, c0 = (AMODE == AMODE_DENSE) ? 0 : (kt0 * BK) % p.Cin;
 
     // direct global -> LDS staging of tile kt into `stage` (one 1-KiB global_load_lds_dwordx4 per wave and 8-row group)
     auto dma_tile = [&](int kt, int stage) {
@@ -238,14 +244,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         __builtin_amdgcn_sched_barrier(0);
         mma(xb, yb);
     };
-    const int nk = p.K / BK;
+    const int nk = kt1;
     // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
     // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
-    dma_tile(0, 0);
+    dma_tile(kt0, kt0 & 1);
     __syncthreads();
     const bool skip_dma = (p.tile_cfg & 16) != 0;  // timing experiment only (results are wrong): no DMA after tile 0
     if (p.dbg == nullptr) {
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt0; kt < nk; ++kt) {
             const int stage = kt & 1;
             if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
             compute(stage);
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     } else {  // phase timers (s_memtime, shader cycles) per wave: [dma issue, compute, barrier wait, total], tuning only
         unsigned long long t_dma = 0, t_cmp = 0, t_bar = 0;
         const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt0; kt < nk; ++kt) {
             const int stage = kt & 1;
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
@@ -272,11 +278,62 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         }
     }
 
+    if constexpr (EPI == EPI_LINEAR) {
+        if (ksplit > 1) {  // fp32 partial tile of this K slice -> workspace [kslice][M][N]; splitk_finish_kernel applies the epilogue
+            VkGemmDesc q = p;
+            q.out = (float*)p.splitk_ws + (size_t)kslice * p.M * p.N;
+            q.ldc = p.N;
+            q.bias = nullptr; q.rowvec = nullptr; q.res1 = nullptr; q.res2 = nullptr;
+            q.alpha = 1.f; q.beta = 0.f;
+            gemm_epilogue<EPI_LINEAR, true, FX, FY, FM, FN>(q, acc, m0, n0, wm, wn, l31, lh);
+            return;
+        }
+    }
     gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh);
 }
 
+// Second pass of a split-K GEMM: out = alpha*(sum_s partial[s] + bias + rowvec + res1) + beta*res2, partials summed in slice order
+// (bitwise reproducible). One thread per 4 consecutive columns of a row.
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const VkGemmDesc p, const int ksplit) {
+    const long long quads = (long long)p.M * (p.N >> 2);
+    const uint16_t* __restrict__ res1 = (const uint16_t*)p.res1;
+    const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < quads; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / (p.N >> 2));
+        const int n = (int)(i - (long long)m * (p.N >> 2)) * 4;
+        const float* ws = (const float*)p.splitk_ws + (size_t)m * p.N + n;
+        float4 a = *(const float4*)ws;
+        for (int s = 1; s < ksplit; ++s) {
+            const float4 b = *(const float4*)(ws + (size_t)s * p.M * p.N);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float v[4] = {a.x, a.y, a.z, a.w};
+        if (p.bias) {
+            const float4 b = *(const float4*)(p.bias + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.rowvec) {
+            const float4 b = *(const float4*)(p.rowvec + (size_t)(m / p.rows_per_vec) * p.ldv + n);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (res1) {
+            const uint2 r = *(const uint2*)(res1 + (size_t)m * p.ld_res1 + n);
+            v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+        if (res2) {
+            const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
+            v[0] += p.beta * bf16_lo(r.x); v[1] += p.beta * bf16_hi(r.x); v[2] += p.beta * bf16_lo(r.y); v[3] += p.beta * bf16_hi(r.y);
+        }
+        if (OUT_F32) *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    }
+}
+
 template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
-int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
+int launch_cfg(const VkGemmDesc* d, hipStream_t stream, int ksplit = 1) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tilesN = (d->N + BN - 1) / BN;
     const int tilesM = (d->M + BM - 1) / BM;
@@ -284,8 +341,14 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream) {
     // Activation rows that at most 4 column-tiles ever read are streamed with the non-temporal policy: they would only evict the
     // weight tile every workgroup shares (measured +6-8 % on the K=320 level-0 projections, -5-11 % when 10+ column tiles re-read A).
     desc.tile_cfg = (desc.tile_cfg & ~32) | ((AMODE == AMODE_DENSE && tilesN <= 4) ? 32 : 0);
-    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN>), dim3(tilesM * tilesN), dim3(WM * WN * 64), 0, stream, desc);
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN>), dim3(tilesM * tilesN * ksplit), dim3(WM * WN * 64), 0, stream, desc, ksplit);
     VK_CHECK_LAUNCH();
+    if (ksplit > 1) {
+        const long long quads = (long long)d->M * (d->N >> 2);
+        const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+        hipLaunchKernelGGL((splitk_finish_kernel<OUT_F32>), dim3(grid), dim3(256), 0, stream, desc, ksplit);
+        VK_CHECK_LAUNCH();
+    }
     return VK_OK;
 }
 
@@ -310,14 +373,33 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
         else if (wgs(256, 128) >= need) cfg = 2;
         else cfg = 1;
     }
+    // Split-K for small-M, deep-K problems (deep UNet levels; every level of a frame-sharded multi-GPU rank): when even the
+    // 128-wide tiles would leave the chip under-filled or ragged, run the LARGEST tile over 2..8 K slices instead, so that
+    // tiles x slices ~ one full round of CUs; fp32 partials go to the caller's workspace and a finishing pass applies the epilogue.
+    int ksplit = 1;
+    if constexpr (EPI == EPI_LINEAR) {
+        if (force == 0 && d->splitk_ws && cfg != 4 && cfg != 3) {
+            const bool ok320s = (AMODE != AMODE_CONV3D) && (d->N % 320 == 0);
+            const int bn = ok320s ? 320 : 256;
+            const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
+            const int nk = d->K / BK;
+            int s = (int)(256 / tiles);
+            if (s > 8) s = 8;
+            if (s > nk / 8) s = nk / 8;  // at least 8 K-steps per slice
+            if (s >= 2 && tiles * s >= 128 && (long long)s * d->M * d->N * 4 <= d->splitk_ws_bytes) {
+                ksplit = s;
+                cfg = ok320s ? 4 : 3;
+            }
+        }
+    }
     if constexpr (EPI != EPI_GEGLU && AMODE != AMODE_CONV3D) {
         // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
         // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
-        if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream);
+        if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream, ksplit);
     }
     // 256x256 runs as SIXTEEN waves (4 per SIMD, 64x64 wave tiles, <= 128 VGPRs): same bytes per FLOP as the 8-wave layout, but twice
     // the waves to cover LDS-read latency, DMA issue and the per-K-step barrier (+5-10 % on GEGLU and the N % 320 != 0 projections).
-    if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 2>(d, stream);
+    if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 2>(d, stream, ksplit);
     if constexpr (EPI != EPI_GEGLU) {
         if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 1>(d, stream);  // 256x128, sixteen 64x32 wave tiles
     }

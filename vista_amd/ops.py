@@ -130,12 +130,28 @@ TILE_CFG = 0  # 0 = auto; tests force 1/2/3 to cover every block-tile variant
 TILE_FLAGS = int(os.environ.get("VISTA_TILE_FLAGS", "0"))  # tuning: 8 = ping-pong schedule, 16 = no-DMA timing experiment
 
 
+SPLITK_WS_BYTES = int(os.environ.get("VISTA_SPLITK_WS_MB", "160")) << 20  # fp32 split-K workspace per device (0 disables split-K)
+_SPLITK_WS = {}
+
+
+def _splitk_workspace():
+    """One workspace per device, reused by every GEMM (all launches go to torch's current stream, hence are ordered)."""
+    dev = torch._C._cuda_getDevice()
+    ws = _SPLITK_WS.get(dev)
+    if ws is None:
+        ws = _SPLITK_WS[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{dev}")
+    return ws
+
+
 GEMM_DBG = None  # tuning only: a u64 CUDA tensor receiving per-wave phase timers of sampled workgroups
 
 
 def _gemm(desc):
     lib = _lib.load()
     desc.tile_cfg = TILE_CFG | TILE_FLAGS
+    if SPLITK_WS_BYTES:
+        ws = _splitk_workspace()
+        desc.splitk_ws, desc.splitk_ws_bytes = _p(ws), ws.numel() * 4
     if GEMM_DBG is not None:
         desc.dbg = _p(GEMM_DBG)
     check(lib.vk_gemm_bf16(C.byref(desc), _stream()), "vk_gemm_bf16")
