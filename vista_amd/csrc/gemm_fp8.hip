@@ -25,7 +25,7 @@ struct F8Args {
 };
 
 template <int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_fp8_kernel(const VkGemmDesc p, const F8Args q) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp8_kernel(const VkGemmDesc p, const F8Args q) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;
@@ -173,7 +173,7 @@ int launch(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
     if constexpr (EPI != EPI_GEGLU) {
         if (cfg == 4) return launch_cfg<EPI, OUT_F32, 4, 2, 2, 5>(d, q, stream);
     }
-    if (cfg == 3) return launch_cfg<EPI, OUT_F32, 2, 4, 4, 2>(d, q, stream);
+    if (cfg == 3) return launch_cfg<EPI, OUT_F32, 4, 4, 2, 2>(d, q, stream);  // sixteen 64x64 wave tiles, 4 waves per SIMD (as in gemm.hip)
     return launch_cfg<EPI, OUT_F32, 2, 2, 2, 2>(d, q, stream);
 }
 
