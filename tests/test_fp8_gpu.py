@@ -91,8 +91,7 @@ def test_geglu_fp8():
     xq, xs = ops.quantize_rows_fp8(x)
     out = ops.linear_fp8(xq, xs, pw)
     # dequantised reference in the ORIGINAL (value | gate) row order
-    idx = torch.arange(nout).reshape(-1, 32)
-    perm = torch.stack([idx, idx + nout], 1).reshape(-1)
+    perm = ops.geglu_perm(nout)
     wd = torch.empty(2 * nout, K)
     wd[perm] = pw.wt[:2 * nout, :K].cpu().view(torch.float8_e4m3fn).float() * pw.scale[:2 * nout].cpu()[:, None]
     h = deq(xq, xs) @ wd.t() + b

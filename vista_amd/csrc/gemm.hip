@@ -360,11 +360,11 @@ template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
     const int force = d->tile_cfg & 7;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (tests / tuning)
     int cfg = force;
-    if (cfg == 4 && EPI == EPI_GEGLU) cfg = 3;  // the GEGLU packing needs 64-column wave tiles
     if (cfg == 4 && AMODE == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
     if (cfg == 0) {
         auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
         const int n256 = (d->N + 255) / 256 * 256;
+        // GEGLU could run on the 256x320 tile since the fragment-local packing, but measured 2-9 % slower there than on 256x256
         const bool ok320 = (EPI != EPI_GEGLU) && (AMODE != AMODE_CONV3D) && (d->N % 320 == 0);
         const bool ok256 = n256 * 10 <= d->N * 11;
         const long long need = 192;  // >= 75 % of the 256 CUs in a single round still beats the smaller, less efficient tiles
@@ -392,7 +392,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
             }
         }
     }
-    if constexpr (EPI != EPI_GEGLU && AMODE != AMODE_CONV3D) {
+    if constexpr (AMODE != AMODE_CONV3D) {
         // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
         // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
         if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream, ksplit);
@@ -400,10 +400,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
     // 256x256 runs as SIXTEEN waves (4 per SIMD, 64x64 wave tiles, <= 128 VGPRs): same bytes per FLOP as the 8-wave layout, but twice
     // the waves to cover LDS-read latency, DMA issue and the per-K-step barrier (+5-10 % on GEGLU and the N % 320 != 0 projections).
     if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 2>(d, stream, ksplit);
-    if constexpr (EPI != EPI_GEGLU) {
-        if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 1>(d, stream);  // 256x128, sixteen 64x32 wave tiles
-    }
-    if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 2, 2>(d, stream);
+    if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 1>(d, stream);  // 256x128, sixteen 64x32 wave tiles
     return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 1, 2>(d, stream);  // 128x128 as eight 32x64 wave tiles, two workgroups per CU
 }
 
@@ -430,7 +427,7 @@ extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
             if (d->amode == AMODE_CONV3D) return f32 ? launch<AMODE_CONV3D, EPI_LINEAR, true>(d, stream) : launch<AMODE_CONV3D, EPI_LINEAR, false>(d, stream);
             return VK_EINVAL;
         case EPI_GEGLU:
-            if (d->amode != AMODE_DENSE || f32 || (d->N % 128) != 0) return VK_EINVAL;
+            if (d->amode != AMODE_DENSE || f32 || (d->N % 32) != 0) return VK_EINVAL;  // whole [16 value | 16 gate] fragments
             return launch<AMODE_DENSE, EPI_GEGLU, false>(d, stream);
         case EPI_TRANS:
             if (d->amode != AMODE_DENSE || f32 || d->S <= 0 || (d->S % 4) != 0) return VK_EINVAL;

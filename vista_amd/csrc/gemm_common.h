@@ -90,8 +90,8 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
             }
         }
     } else if (EPI == EPI_GEGLU) {
-        // packed weight rows: every 64-row wave slice = [32 value rows | 32 gate rows]; fi=0 value, fi=1 gate
-        static_assert(EPI != EPI_GEGLU || FN == 2, "GEGLU packing assumes a 64-column wave tile");
+        // packed weight rows: every 32-row fragment = [16 value rows | 16 gate rows] of the SAME 16 output columns, so the value quad g
+        // (g = 0, 1) and its gate quad g + 2 sit in the same lane whatever the wave tile width -- any block tile can run GEGLU.
         const float* __restrict__ bias = p.bias;
         const int nout = p.N >> 1;
         const bool wide = (nout % 16 == 0) && (p.ldc % 8 == 0) && (((size_t)p.out & 15) == 0);
@@ -99,31 +99,32 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
         for (int fj = 0; fj < FY; ++fj) {
             const int m = m0 + wm * MW + fj * 32 + l31;
             if (m >= p.M) continue;
-            uint2 packed[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int np = n0 + wn * 64 + 8 * g + 4 * lh;       // packed row of the value part
-                const int nc = (n0 >> 1) + wn * 32 + 8 * g + 4 * lh;  // output column
-                packed[g] = make_uint2(0, 0);
-                if (nc >= nout) continue;
-                float a[4], gt[4];
+            for (int fi = 0; fi < FX; ++fi) {
+                const int nfrag = n0 + wn * NW + fi * 32;  // first packed row of the fragment
+                uint2 packed[2];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] = acc[0][fj][4 * g + e]; gt[e] = acc[1][fj][4 * g + e]; }
-                if (bias) {
-                    const float4 ba = *(const float4*)(bias + np);
-                    const float4 bg = *(const float4*)(bias + np + 32);
-                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
-                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                for (int g = 0; g < 2; ++g) {
+                    const int np = nfrag + 8 * g + 4 * lh;           // packed row of the value part; its gate is 16 rows further
+                    const int nc = (nfrag >> 1) + 8 * g + 4 * lh;    // output column
+                    packed[g] = make_uint2(0, 0);
+                    if (nc >= nout) continue;
+                    float a[4], gt[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = acc[fi][fj][4 * g + e]; gt[e] = acc[fi][fj][4 * (g + 2) + e]; }
+                    if (bias) {
+                        const float4 ba = *(const float4*)(bias + np);
+                        const float4 bg = *(const float4*)(bias + np + 16);
+                        a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                        gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                    }
+                    packed[g].x = pack_bf16(a[0] * gelu_erf_f(gt[0]), a[1] * gelu_erf_f(gt[1]));
+                    packed[g].y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
+                    if (!wide) *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + nc) = packed[g];
                 }
-                packed[g].x = pack_bf16(a[0] * gelu_erf_f(gt[0]), a[1] * gelu_erf_f(gt[1]));
-                packed[g].y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
-                if (!wide) *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + nc) = packed[g];
-            }
-            if (wide) {
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {
-                    const int nb = (n0 >> 1) + wn * 32 + 16 * gp;
-                    const uint4 w = widen_pair(packed[2 * gp], packed[2 * gp + 1]);
+                if (wide) {
+                    const int nb = nfrag >> 1;  // 16 output columns of this fragment: 8 per lane half after the swap
+                    const uint4 w = widen_pair(packed[0], packed[1]);
                     if (nb < nout) *(uint4*)((uint16_t*)p.out + (size_t)m * p.ldc + nb + 8 * lh) = w;
                 }
             }

@@ -89,17 +89,20 @@ def pack_linear_cat(weights, device="cuda"):
     return _finish_pack(torch.cat([w.detach().float() for w in weights], 0), None, device)
 
 
+def geglu_perm(nout):
+    """Row order of a packed GEGLU weight: every 32-row MFMA fragment holds [16 value rows | the 16 gate rows of the same output
+    columns], so the GEMM epilogue forms value*gelu(gate) inside a lane for any block / wave tile shape."""
+    if nout % 16:
+        raise ValueError("GEGLU width must be a multiple of 16")
+    idx = torch.arange(nout).reshape(-1, 16)
+    return torch.stack([idx, idx + nout], 1).reshape(-1)  # [v-block0, g-block0, v-block1, g-block1, ...]
+
+
 def pack_geglu(weight, bias, device="cuda"):
-    """GEGLU.proj weight [2*Nout][K]: value rows then gate rows (attention.py:85-92). Packed so that every 128-row
-    tile holds 2 x [32 value rows | their 32 gate rows] and the GEMM epilogue can form value*gelu(gate) in-lane."""
+    """GEGLU.proj weight [2*Nout][K]: value rows then gate rows (attention.py:85-92), packed in `geglu_perm` order."""
     w = weight.detach().float()
     b = bias.detach().float()
-    n2, _ = w.shape
-    nout = n2 // 2
-    if nout % 64:
-        raise ValueError("GEGLU width must be a multiple of 64")
-    idx = torch.arange(nout).reshape(-1, 32)           # blocks of 32 output columns
-    perm = torch.stack([idx, idx + nout], 1).reshape(-1)  # [v-block0, g-block0, v-block1, g-block1, ...]
+    perm = geglu_perm(w.shape[0] // 2)
     return _finish_pack(w[perm], b[perm], device, geglu=True)
 
 
@@ -346,11 +349,7 @@ def pack_geglu_fp8(weight, bias, device="cuda"):
     """GEGLU.proj in the value/gate-interleaved row order of pack_geglu, quantised per packed row."""
     w = weight.detach().float().cpu()
     b = bias.detach().float().cpu()
-    nout = w.shape[0] // 2
-    if nout % 64:
-        raise ValueError("GEGLU width must be a multiple of 64")
-    idx = torch.arange(nout).reshape(-1, 32)
-    perm = torch.stack([idx, idx + nout], 1).reshape(-1)
+    perm = geglu_perm(w.shape[0] // 2)
     return _finish_pack_fp8(w[perm], b[perm], device, geglu=True)
 
 
