@@ -93,7 +93,7 @@ int vk_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, int32_t cols
  * temporal ResBlock whose statistics cover (C/32, T, H, W)).
  * Replaces GroupNorm32/Normalize + nn.SiLU: vwm/modules/diffusionmodules/util.py:196-216, attention.py:141-142,
  * openaimodel.py:195-199,227-230, video_model.py:434-436.
- * stats_ws: f32 workspace of 64*(n_img/frames_per_group) + 64*n_img*ceil(S/128) floats (fixed-order partial sums:
+ * stats_ws: f32 workspace of 64*(n_img/frames_per_group) + 64*n_img*ceil(S/32) floats (fixed-order partial sums:
  * results are bitwise reproducible, no atomics). */
 int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const float* beta, float* stats_ws,
                            int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group, float eps, int32_t silu,
@@ -101,7 +101,7 @@ int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma, const flo
 
 /* The two halves of vk_groupnorm_silu_bf16, for pixel-sharded multi-GPU runs of the temporal ResBlock: `sums` is
  * [n_img/frames_per_group][64] = raw [32 sums | 32 sums of squares] over the LOCAL elements (all-reduce them across ranks),
- * `partial_ws` needs 64*n_img*ceil(S/128) floats, `count` is the GLOBAL element count per (image-group, channel-group). */
+ * `partial_ws` needs 64*n_img*ceil(S/32) floats, `count` is the GLOBAL element count per (image-group, channel-group). */
 int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C,
                             int32_t frames_per_group, void* stream);
 int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img,

@@ -19,12 +19,12 @@ constexpr int GN_TOK = 128;  // tokens per workgroup
 
 // stats pass 1: per (image, 128-token chunk) partial (sum, sumsq) of the 32 groups, reduced in a FIXED order
 // (thread partials -> LDS [r][channel] -> per-channel over r -> per-group over channels): bitwise reproducible.
-__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial, int S, int C, int CG, int R) {
+__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial, int S, int C, int CG, int R, int tok_per_wg) {
     extern __shared__ float lds[];  // [2][R][C]
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
-    const int tok0 = blockIdx.x * GN_TOK;
-    const int tok1 = min(tok0 + GN_TOK, S);
+    const int tok0 = blockIdx.x * tok_per_wg;
+    const int tok1 = min(tok0 + tok_per_wg, S);
     const int chunk = tid % CG, r = tid / CG;
     const int cpg = C >> 5;
     float* lsum = lds;
@@ -114,11 +114,11 @@ __global__ void gn_finalize_level2_kernel(const float* __restrict__ partial, flo
 
 __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ stats, int S, int C, int CG, int R,
-                                int frames_per_group, float inv_cnt, float eps, int do_silu) {
+                                int frames_per_group, float inv_cnt, float eps, int do_silu, int tok_per_wg) {
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
-    const int tok0 = blockIdx.x * GN_TOK;
-    const int tok1 = min(tok0 + GN_TOK, S);
+    const int tok0 = blockIdx.x * tok_per_wg;
+    const int tok1 = min(tok0 + tok_per_wg, S);
     const int chunk = tid % CG, r = tid / CG;
     if (r >= R) return;
     const int cpg = C >> 5;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
 }  // namespace
 
 namespace {
-struct GnGeom { int CG, R, threads, nchunks, ngroups; };
+struct GnGeom { int CG, R, threads, nchunks, ngroups, tok; };
 inline bool gn_geom(int n_img, int S, int C, int fpg, GnGeom& g) {
     if (n_img <= 0 || S <= 0 || C <= 0 || (C % 32) != 0 || (C % 8) != 0 || C > 8192) return false;
     if (fpg <= 0 || (n_img % fpg) != 0) return false;
@@ -246,7 +246,10 @@ inline bool gn_geom(int n_img, int S, int C, int fpg, GnGeom& g) {
     g.R = 256 / g.CG;
     if (g.R < 1) g.R = 1;
     g.threads = ((g.CG * g.R + 63) / 64) * 64;
-    g.nchunks = (S + GN_TOK - 1) / GN_TOK;
+    // wide channels leave one token row per pass (R = 1): 32 tokens per workgroup instead of 128, so the deep, small levels
+    // (C >= 1024, S = 144 / 576) launch enough workgroups to hide their serial token loop
+    g.tok = (g.R >= 2) ? GN_TOK : 32;
+    g.nchunks = (S + g.tok - 1) / g.tok;
     g.ngroups = n_img / fpg;
     return true;
 }
@@ -259,7 +262,7 @@ extern "C" int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partia
     if (!x || !sums || !partial_ws || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
     dim3 grid(g.nchunks, n_img);
     const size_t lds_bytes = (size_t)2 * g.R * C * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, partial_ws, S, C, g.CG, g.R);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, partial_ws, S, C, g.CG, g.R, g.tok);
     VK_CHECK_LAUNCH();
     const int nparts = frames_per_group * g.nchunks;
     if (nparts <= 256) {
@@ -283,9 +286,10 @@ extern "C" int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamm
     hipStream_t stream = (hipStream_t)stream_;
     GnGeom g;
     if (!x || !y || !gamma || !beta || !sums || count <= 0.f || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
+    const int tok_per_wg = g.tok;
     dim3 grid(g.nchunks, n_img);
     hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (uint16_t*)y, gamma, beta, sums, S, C, g.CG, g.R,
-                       frames_per_group, 1.f / count, eps, silu);
+                       frames_per_group, 1.f / count, eps, silu, tok_per_wg);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }

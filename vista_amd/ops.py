@@ -438,7 +438,7 @@ def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None):
     n_img, S, Cc = x.shape
     if out is None:
         out = torch.empty_like(x)
-    ws = torch.empty(((n_img // frames_per_group) + n_img * ((S + 127) // 128)) * 64, dtype=F32, device=x.device)
+    ws = torch.empty(((n_img // frames_per_group) + n_img * ((S + 31) // 32)) * 64, dtype=F32, device=x.device)
     lib = _lib.load()
     check(lib.vk_groupnorm_silu_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), n_img, S, Cc, frames_per_group, float(eps),
                                      1 if silu else 0, _stream()), "vk_groupnorm_silu_bf16")
@@ -453,7 +453,7 @@ def groupnorm_sharded(x, gamma, beta, eps, silu, frames_per_group, allreduce, gl
     out = torch.empty_like(x)
     ng = n_img // frames_per_group
     sums = torch.empty(ng * 64, dtype=F32, device=x.device)
-    part = torch.empty(n_img * ((S + 127) // 128) * 64, dtype=F32, device=x.device)
+    part = torch.empty(n_img * ((S + 31) // 32) * 64, dtype=F32, device=x.device)
     lib = _lib.load()
     check(lib.vk_groupnorm_stats_bf16(_p(x), _p(sums), _p(part), n_img, S, Cc, frames_per_group, _stream()), "vk_groupnorm_stats_bf16")
     allreduce(sums)
