@@ -402,3 +402,61 @@ def test_conv_t3_halo_frames_equal_a_longer_clip():
         nxt = x4[:, t1].contiguous() if t1 < T else None
         out = ops.conv_t3(loc, pw, t1 - t0, S, halo_prev=prev, halo_next=nxt).view(B, t1 - t0, S, C)
         assert torch.equal(out, full[:, t0:t1]), (t0, t1)
+
+
+# ------------------------------------------------------------------------------------------------ split-K
+def _with_and_without_splitk(fn):
+    """Runs fn() with the split-K workspace enabled and disabled; returns (split, plain)."""
+    ops = _ops()
+    a = fn()
+    saved, ops.SPLITK_WS_BYTES = ops.SPLITK_WS_BYTES, 0
+    try:
+        b = fn()
+    finally:
+        ops.SPLITK_WS_BYTES = saved
+    return a, b
+
+
+def test_splitk_dense_matches_reference_and_plain_kernel():
+    """M = 4032 rows (a level-2 activation of one 8-GPU rank), N = 1280, K = 5120: 64 tiles -> 4 K slices."""
+    ops = _ops()
+    M, N, K = 4032, 1280, 5120
+    x = rnd(M, K)
+    w = rnd(N, K, scale=K ** -0.5, seed=1)
+    b = rnd(N, seed=2).float()
+    r1 = rnd(M, N, seed=3)
+    r2 = rnd(M, N, seed=4)
+    pw = ops.pack_linear(w, b)
+    split, plain = _with_and_without_splitk(lambda: ops.linear(x, pw, res1=r1, res2=r2, alpha=0.6, beta=0.4))
+    ref = 0.6 * (x.float() @ w.float().t().cuda() + b.cuda() + r1.float()) + 0.4 * r2.float()
+    close(split, ref, "split-K dense")
+    close(plain, ref, "plain dense")
+    # a different fp32 summation order is allowed: the two results are at most one bf16 ulp apart
+    assert (split.float() - plain.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+    s32, p32 = _with_and_without_splitk(lambda: ops.linear(x, pw, out_f32=True))
+    assert torch.allclose(s32, p32, rtol=1e-4, atol=1e-4) and torch.equal(s32, ops.linear(x, pw, out_f32=True)), "split-K must be repeatable"
+    assert not torch.equal(s32, p32), "the split-K path was not taken (its fp32 summation order differs from the plain kernel's)"
+
+
+def test_splitk_conv3x3_and_temporal_conv():
+    """Level-3 convs of the UNet (N = 50 images, 9x16 pixels, 1280 channels): 116 tiles of 256x320 -> 2 K slices."""
+    ops = _ops()
+    n, H, W, C = 50, 9, 16, 1280
+    x = rnd(n, H * W, C)
+    w = rnd(C, C, 3, 3, scale=(9 * C) ** -0.5, seed=1)
+    b = rnd(C, seed=2).float()
+    rv = rnd(n, C, seed=3).float()
+    pw = ops.pack_conv3x3(w, b)
+    split, plain = _with_and_without_splitk(lambda: ops.conv3x3(x, pw, n, H, W, rowvec=rv)[0])
+    ref = _nchw2tok(F.conv2d(_tok2nchw(x, n, H, W), w.float().cuda(), b.cuda(), padding=1)) + rv.cuda()[:, None, :]
+    close(split, ref, "split-K conv3x3")
+    close(plain, ref, "plain conv3x3")
+    wt = rnd(C, C, 3, 1, 1, scale=(3 * C) ** -0.5, seed=5)
+    pwt = ops.pack_conv_t3(wt, b)
+    T, S = 25, H * W
+    st, pt = _with_and_without_splitk(lambda: ops.conv_t3(x, pwt, T, S, res2=x, alpha=0.3, beta=1.0))
+    x5 = x.float().view(2, T, S, C).permute(0, 3, 1, 2)[..., None]
+    reft = F.conv3d(x5, wt.float().cuda(), b.cuda(), padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(n, S, C)
+    reft = 0.3 * reft + x.float()
+    close(st, reft, "split-K temporal conv")
+    close(pt, reft, "plain temporal conv")
