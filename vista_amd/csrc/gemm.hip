@@ -9,15 +9,19 @@
 // W is [Npad][K] with K contiguous (= nn.Linear.weight layout; conv weights are packed [Cout][tap][Cin]).
 //
 // Tiling (template): block tile BM x BN x 64 with WM x WN waves, each wave FM x FN MFMA 32x32x16 bf16 tiles, fp32 accumulate.
-//   256x256 (8 waves 2x4, wave tile 128x64)  large-N GEMMs/convs: halves LDS-fill and cuts fragment-read bytes per FLOP
-//   256x320 (8 waves 4x2, wave tile  64x160) N a multiple of 320 (every channel count of the shipped UNet): no padded
-//                                            columns, and the conv gather of A runs once per 320 output channels
-//   256x128 (8 waves 4x2, wave tile  64x64)  other narrow N
-//   128x128 (4 waves 2x2, wave tile  64x64)  small problems (embedding MLPs, context vectors)
+// Every layout keeps a wave at <= 128 VGPRs, i.e. FOUR waves per SIMD: co-resident waves, not a hand-built phase schedule, are
+// what covers LDS-read latency, LDS-DMA issue and the per-K-step barrier on this chip (profiles/r01_vendor_blas_yardstick.txt).
+//   256x320 (16 waves 8x2, wave tile 32x160, single-buffered fragments)  N a multiple of 320 (every channel count of the
+//                                            shipped UNet): no padded columns, the conv gather of A runs once per 320 channels
+//   256x256 (16 waves 4x4, wave tile 64x64)  GEGLU and N % 320 != 0
+//   256x128 (16 waves 4x4, wave tile 64x32)  other narrow N
+//   128x128 ( 8 waves 4x2, wave tile 32x64)  small problems, two workgroups per CU
+// Small-M, deep-K LINEAR problems run the largest tile over 2..8 K slices (split-K; fp32 partials in the caller's workspace,
+// fixed-order finishing pass) so that tiles x slices fills the chip.
 // LDS: two stages of (A tile + W tile); rows are 128 B (64 bf16) and the 16-B chunk index is XOR-swizzled
 // with (row>>1)&7 so the ds_read_b128 fragment reads are bank-conflict free. Tiles stream HBM/L2 -> LDS by LDS-DMA
 // (global_load_lds_dwordx4; the swizzle, the conv gathers and the zero padding live in the per-lane SOURCE address): tile t+1
-// lands while the MFMAs consume tile t, one barrier per K-step, fragment reads double-buffered in registers.
+// lands while the MFMAs consume tile t, one barrier per K-step, fragment reads double-buffered in registers where they fit.
 // The MFMA is issued "swapped" (weights are the row/A operand, activations the column/B operand) so that a lane
 // owns one output row m and 4 consecutive output columns per accumulator quad -> 8-byte bf16x4 stores and
 // per-lane-contiguous fused epilogues (bias, per-image row vector, residuals, GEGLU).

@@ -11,7 +11,6 @@ enum { EPI_LINEAR = 0, EPI_GEGLU = 1, EPI_TRANS = 2 };
 
 constexpr int BK = 64;
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // Fused epilogue shared by the GEMM kernels. Accumulator element r = 4*g + e of tile (fi,fj): X-row = 32*fi + 8*g + 4*lh + e,
 // Y-row = 32*fj + l31 (X = weights / Y = activations, swapped for EPI_TRANS). MW/NW = wave-tile extents along m / n.

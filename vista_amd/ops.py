@@ -130,7 +130,7 @@ def pack_conv_t3(weight, bias=None, device="cuda", cin_pad=None):
 
 # ---------------------------------------------------------------------------------------------- GEMM family
 TILE_CFG = 0  # 0 = auto; tests force 1/2/3 to cover every block-tile variant
-TILE_FLAGS = int(os.environ.get("VISTA_TILE_FLAGS", "0"))  # tuning: 8 = ping-pong schedule, 16 = no-DMA timing experiment
+TILE_FLAGS = int(os.environ.get("VISTA_TILE_FLAGS", "0"))  # tuning only: 16 = no-DMA timing experiment (results invalid)
 
 
 SPLITK_WS_BYTES = int(os.environ.get("VISTA_SPLITK_WS_MB", "160")) << 20  # fp32 split-K workspace per device (0 disables split-K)
