@@ -13,6 +13,10 @@
 //   LDS-DMA (global_load_lds_dwordx4; the row permutation and the bank swizzle live in the per-lane SOURCE address,
 //   keys past the sequence end read a zero word), 2-stage ring, one barrier per 64-key tile.
 //   LDS swizzle (both tiles, 128-B rows): 16-B chunk ^= (row>>1)&7 -> ds_read_b128 conflict-free.
+//   Occupancy: 121 VGPRs, 32 KiB LDS -> TWO workgroups (16 waves) per CU; the co-resident workgroups are what overlaps one
+//   wave's softmax VALU work with another's MFMAs. Restructurings that needed > 128 VGPRs (two score tiles in flight, phase-offset
+//   wave halves, row sums / max subtraction moved into extra MFMAs) all measured slower (profiles/r01_vendor_blas_yardstick.txt).
+//   Online softmax with a deferred re-base: O and l are rescaled only when a row maximum grows by more than 2^6 (RESCALE_THR).
 //
 // vk_attn_temporal_bf16 -- per-pixel attention over the T (<=32) frames (VideoTransformerBlock.attn1;
 //   vwm/modules/video_attention.py:116-127, attention.py:384-399): one wave per (batch, pixel, head); Q/K
