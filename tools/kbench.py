@@ -2,7 +2,6 @@
 Usage (GPU box): python tools/kbench.py [--quick]"""
 import json
 import sys
-import time
 
 import torch
 

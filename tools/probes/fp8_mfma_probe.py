@@ -1,4 +1,4 @@
-import ctypes, os, subprocess, sys, torch
+import ctypes, os, torch
 here = os.path.dirname(os.path.abspath(__file__))
 so = os.path.join(here, "fp8_probe.hsaco")
 # load via hipModule (kernels are extern "C" __global__): use torch's current context through ctypes on libamdhip64

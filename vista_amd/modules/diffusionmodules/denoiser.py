@@ -5,7 +5,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...util import append_dims, instantiate_from_config
+from ...util import instantiate_from_config
 from .denoiser_scaling import DenoiserScaling
 
 

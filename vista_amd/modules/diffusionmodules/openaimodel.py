@@ -6,7 +6,7 @@
       h = conv(silu(GN32(h)))          second conv; `skip(x) + h` is its residual epilogue
   Upsample (openaimodel.py:86-103): nearest x2 fused into the conv's gather; Downsample (:136): stride-2 gather.
 """
-from typing import Iterable, Optional
+from typing import Iterable
 
 import torch.nn as nn
 

@@ -11,7 +11,6 @@ unchanged, and only the 25x25 attention core gathers across frames (vk_attn_temp
                                        vector, added as a row vector in the attn1 out-projection epilogue
       x = ff(norm3(x)) + x             the AlphaBlender mix with the spatial branch is fused into this GEMM's epilogue
 """
-import torch
 import torch.nn as nn
 
 from .. import ops
