@@ -143,3 +143,37 @@ def test_product_path_refuses_cpu():
     # parameter containers carry no eager arithmetic
     with pytest.raises(RuntimeError):
         net.time_embed[0](torch.zeros(1, 64))
+
+
+def test_weight_packing_layouts_on_cpu():
+    """Host-side packing (no kernel launch): GEGLU fragment-local row order, conv tap-major K order, zero padding, fp8 scales."""
+    from vista_amd import ops
+    nout, K = 64, 128
+    perm = ops.geglu_perm(nout)
+    assert sorted(perm.tolist()) == list(range(2 * nout)), "a permutation of the 2*nout rows"
+    blocks = perm.view(-1, 32)
+    assert torch.equal(blocks[:, :16] + nout, blocks[:, 16:]), "every 32-row fragment = [16 value rows | their 16 gate rows]"
+    assert torch.equal(blocks[:, 0], torch.arange(0, nout, 16))
+    w = torch.randn(2 * nout, K)
+    b = torch.randn(2 * nout)
+    pg = ops.pack_geglu(w, b, device="cpu")
+    assert pg.geglu and pg.N == 2 * nout and pg.K == K and pg.wt.shape[0] == 320  # rows padded so that every block tile (<= 320 wide) reads whole tiles
+    assert torch.equal(pg.wt[:2 * nout].float(), w[perm].to(torch.bfloat16).float()) and pg.wt[2 * nout:].abs().sum() == 0
+    assert torch.equal(pg.bias[:2 * nout], b[perm])
+    # conv3x3: [Cout][ky][kx][Cin padded to 64]
+    wc = torch.randn(8, 3, 3, 3)
+    pc = ops.pack_conv3x3(wc, None, device="cpu")
+    assert pc.N == 8 and pc.K == 9 * 64
+    v = pc.wt[:8].float().view(8, 3, 3, 64)
+    assert torch.equal(v[..., :3], wc.permute(0, 2, 3, 1).to(torch.bfloat16).float()) and v[..., 3:].abs().sum() == 0
+    # odd Cout is rounded up to the 4-column epilogue quad with zero rows / bias
+    pl = ops.pack_linear(torch.randn(3, 64), torch.randn(3), device="cpu")
+    assert pl.N == 4 and pl.wt[3:].abs().sum() == 0 and pl.bias[3:].abs().sum() == 0
+    # fp8: per-output-channel scales reproduce the weights to e4m3 precision (3 mantissa bits -> <= 2^-4 relative per element)
+    w8 = torch.randn(40, 320) * torch.logspace(-2, 1, 40)[:, None]
+    p8 = ops.pack_linear_fp8(w8, None, device="cpu")
+    assert p8.Kp == 384 and p8.K == 320 and p8.wt.dtype == torch.uint8 and p8.wt[:, 320:].sum() == 0
+    deq = p8.wt[:40, :320].view(torch.float8_e4m3fn).float() * p8.scale[:40, None]
+    assert ((deq - w8).abs() <= w8.abs() * 2 ** -4 + p8.scale[:40, None] * 2 ** -9 + 1e-12).all()
+    with pytest.raises(ValueError):
+        ops.geglu_perm(24)
