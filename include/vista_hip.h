@@ -35,16 +35,29 @@ typedef struct VkGemmDesc {
     int32_t H, Wd, Cin, Hout, Wout, stride, ups; /* CONV3X3: source H x Wd (before the x`ups` nearest upsample)   */
     int32_t T, S;        /* TEMPORAL3: frames per clip, tokens per frame. EPI_TRANS: S = tokens per image.
                             CONV3D (3x3x3, pad 1 over [frames][H][Wd][Cin], K = 27*Cin): T = frames per clip        */
-    int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning); |16 = timing-only no-DMA experiment.
-                            Weight rows
+    int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning). Weight rows
                             are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                                                      */
     const void* halo_prev; /* TEMPORAL3, frame-sharded runs: bf16 [clips][S][Cin] frame preceding / following the local frame range   */
     const void* halo_next; /* (from the neighbour rank); NULL = the conv's zero padding at the window ends                               */
-    void* dbg;           /* tuning only: if non-NULL, per-wave phase timers (u64 x4 per wave, 16 waves per sampled block)  */
     void* splitk_ws;     /* optional fp32 workspace for split-K of small-M, deep-K LINEAR problems (NULL = never split); must not be  */
     int64_t splitk_ws_bytes; /* shared by GEMMs in flight on different streams. A split needs slices * M * N * 4 bytes.              */
     int32_t asym_pad;    /* CONV3X3: 0 = zero padding 1 on all sides; 1 = padding (0,1,0,1) = bottom/right only, the VAE encoder's
                             Downsample (vwm/modules/diffusionmodules/model.py:77-81: F.pad(x, (0,1,0,1)) then conv stride 2 pad 0)  */
+    /* ---- DENSE two-source A: the channel concat of the UNet skip (video_model.py:493) folded into the loader ---- */
+    int32_t k_split;     /* columns k >= k_split of A come from A2[m][k - k_split]; a multiple of 64; used only when A2 != NULL    */
+    const void* A2;      /* bf16 [M][lda2] or NULL                                                                              */
+    int32_t lda2;
+    /* ---- LayerNorm folded into the consumer GEMM (attention.py:514-524, video_attention.py:119-137: `Linear(LayerNorm(x))`):
+     *   LN(x) W^T + b = rstd_m * (x W'^T - mean_m * s_n) + t_n,  W' = gamma (.) W,  s_n = sum_k W'[n][k],  t_n = (W beta)_n + b_n.
+     * Wt holds W', bias holds t, ln_colsum holds s (of the bf16-rounded W' so that the mean term cancels exactly); mean_m / rstd_m
+     * come from per-row partial sums (sum x, sum x^2) over column blocks of x, summed here in a fixed order. DENSE only, K = LN width. */
+    int32_t ln_parts;    /* number of partial-sum slabs                                                                         */
+    const float* ln_stats;  /* f32 [ln_parts][M][2] or NULL (= no LayerNorm fold)                                               */
+    const float* ln_colsum; /* f32 [pad(N)] (EPI_GEGLU: packed row order)                                                       */
+    float ln_eps;
+    /* ---- producer side of the same fold: emit the row sums of the bf16-rounded OUTPUT of this GEMM (EPI_LINEAR, bf16 out) ---- */
+    float* rowstat_out;  /* f32 [vk_gemm_rowstat_parts(desc)][M][2] or NULL; one slab per (column tile, wave column)               */
+    const float* rowvec2; /* f32 [M/rows_per_vec][ldv] or NULL, added with beta: out = alpha*(...) + beta*(res2 + rowvec2[row/rows_per_vec]) */
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
@@ -52,6 +65,10 @@ typedef struct VkGemmDesc {
  *   vwm/modules/diffusionmodules/openaimodel.py:136 (Downsample), :84,100-102 (Upsample), :195-199,227-234 (ResBlock convs), :241 (skip)
  *   vwm/modules/diffusionmodules/video_model.py:38-52 (3x1x1 temporal conv), :148-157,176-182 (embedding MLPs), :189,438 (in/out conv) */
 int vk_gemm_bf16(const VkGemmDesc* d, void* stream);
+
+/* Number of partial-sum slabs vk_gemm_bf16 would write to d->rowstat_out for this problem (depends on the block tile the launcher
+ * picks: column tiles x wave columns); > 0, or a negative error code. Pure host function, no launch. */
+int vk_gemm_rowstat_parts(const VkGemmDesc* d);
 
 /* fp8 (OCP e4m3) variant of the DENSE GEMM for the UNet's Linear / 1x1 projections (BASELINE.json config 5: "fp8 1x1
  * conv-as-GEMM path"; same reference call sites as vk_gemm_bf16's DENSE mode: attention.py:268-285,97-128, video_attention.py).
@@ -114,6 +131,18 @@ int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const fl
 int vk_layernorm_bf16(const void* x, void* y, void* sum_out, const float* gamma, const float* beta,
                       const float* addvec, int32_t rows, int32_t C, int32_t rows_per_vec, int32_t ldv, float eps,
                       void* stream);
+
+/* Row sums for a LayerNorm folded into the consumer GEMM (VkGemmDesc.ln_stats with ln_parts = 1) when the tensor was not produced
+ * by a GEMM epilogue on this rank (pixel-sharded temporal block after the all-to-all): stats[row] = (sum_c x, sum_c x^2) of
+ * x[rows][ldx] (first C columns), fixed order. Read-only pass: half the traffic of vk_layernorm_bf16. C % 8 == 0, C <= 1536. */
+int vk_rowstats_bf16(const void* x, float* stats, int32_t rows, int32_t C, int64_t ldx, void* stream);
+
+/* vk_groupnorm_silu_bf16 over the channel concat [x1 | x2] (C1 + C2 channels, both token-major, C1 % 8 == C2 % 8 == 0) without
+ * materialising it: the `torch.cat([h, hs.pop()], dim=1)` of the UNet's output blocks (video_model.py:493) feeding the ResBlock's
+ * first GroupNorm32 (openaimodel.py:195-199). y is [n_img][S][C1+C2]. stats_ws as for vk_groupnorm_silu_bf16. */
+int vk_groupnorm_silu_cat_bf16(const void* x1, const void* x2, void* y, const float* gamma, const float* beta, float* stats_ws,
+                               int32_t n_img, int32_t S, int32_t C1, int32_t C2, int32_t frames_per_group, float eps, int32_t silu,
+                               void* stream);
 
 /* ------------------------------------------------------------------ elementwise / layout */
 /* out[m][0:C1] = a[m][:], out[m][C1:C1+C2] = b[m][:]  (channel concat of the UNet skip: video_model.py:493) */

@@ -23,7 +23,7 @@ def test_abi_header_table_and_library_agree():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} missing from libvista_hip.so"
-    assert _lib.load().vk_abi_version() == 1
+    assert _lib.load().vk_abi_version() == _lib.ABI_VERSION
 
 
 def test_gemm_desc_layout_matches_header():

@@ -23,14 +23,20 @@ class VkGemmDesc(C.Structure):
         ("alpha", _f32), ("beta", _f32),
         ("amode", _i32), ("epi", _i32), ("out_f32", _i32),
         ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Hout", _i32), ("Wout", _i32), ("stride", _i32), ("ups", _i32),
-        ("T", _i32), ("S", _i32), ("tile_cfg", _i32), ("halo_prev", _vp), ("halo_next", _vp), ("dbg", _vp), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("asym_pad", _i32),
+        ("T", _i32), ("S", _i32), ("tile_cfg", _i32), ("halo_prev", _vp), ("halo_next", _vp), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("asym_pad", _i32),
+        ("k_split", _i32), ("A2", _vp), ("lda2", _i32),
+        ("ln_parts", _i32), ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_eps", _f32),
+        ("rowstat_out", _vp), ("rowvec2", _vp),
     ]
 
+
+ABI_VERSION = 2  # vk_abi_version() of the library this table mirrors
 
 # name -> argtypes; every entry returns int. Must list every symbol include/vista_hip.h declares
 # (tests/test_abi.py checks the header against this table and against the built library).
 SIGNATURES = {
     "vk_gemm_bf16": [C.POINTER(VkGemmDesc), _vp],
+    "vk_gemm_rowstat_parts": [C.POINTER(VkGemmDesc)],
     "vk_gemm_fp8": [C.POINTER(VkGemmDesc), _vp, _vp, _i32, _vp],
     "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
@@ -40,6 +46,8 @@ SIGNATURES = {
     "vk_groupnorm_stats_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vk_groupnorm_apply_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "vk_layernorm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_rowstats_bf16": [_vp, _vp, _i32, _i32, _i64, _vp],
+    "vk_groupnorm_silu_cat_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vk_concat_channels_bf16": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "vk_nchw_to_tokens_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vk_tokens_to_nchw_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
@@ -80,6 +88,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch, surfaced loudly
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    if lib.vk_abi_version() != ABI_VERSION:
+        raise VistaHipError(f"{LIB_PATH} has ABI version {lib.vk_abi_version()}, this package expects {ABI_VERSION}: rebuild it "
+                            "(python -m vista_amd.build --force)")
     _lib = lib
     return lib
 

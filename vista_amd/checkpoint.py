@@ -17,13 +17,16 @@ DECODER_PREFIX = "first_stage_model.decoder."
 _LORA = (("q_adapter_down", "q_adapter_up", "to_q"), ("k_adapter_down", "k_adapter_up", "to_k"), ("v_adapter_down", "v_adapter_up", "to_v"))
 
 
-def load_checkpoint(path):
-    """-> flat {name: tensor}. `.safetensors` via safetensors.torch.load_file, `.ckpt` via torch.load()['state_dict']."""
+def load_checkpoint(path, trust_pickle=False):
+    """-> flat {name: tensor}. `.safetensors` via safetensors.torch.load_file, `.ckpt` via torch.load()['state_dict'].
+    A `.ckpt` is a pickle: it is read with weights_only=True (tensors and plain containers only -- enough for a Lightning checkpoint's
+    state_dict); `trust_pickle=True` is the explicit opt-in to the reference's unrestricted torch.load (sample_utils.py:60-64), which
+    executes whatever the file contains."""
     if path.endswith("safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
     if path.endswith("ckpt"):
-        blob = torch.load(path, map_location="cpu")
+        blob = torch.load(path, map_location="cpu", weights_only=not trust_pickle)
         return blob["state_dict"]
     raise NotImplementedError("Please convert the checkpoint to safetensors first")
 

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         if (m >= p.M) m = p.M - 1;
         if (AMODE == AMODE_DENSE) {
             aptr[i] = Ag + (size_t)m * p.lda + lsrc * 8;
-            a_y0[i] = a_x0[i] = 0;
+            a_y0[i] = m;  // row index, for the second source of a channel-concatenated A
+            a_x0[i] = 0;
         } else if (AMODE == AMODE_CONV3X3) {
             const int hw = p.Hout * p.Wout;
             const int img = m / hw;
@@ -130,14 +131,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             if (RPP * (i + 1) <= BN || RPP * i + 8 * wave_u < BN)  // wave-uniform: waves past the tile's last row skip the partial pass
                 __builtin_amdgcn_global_load_lds((gptr_t)(wptr[i] + k0), (lptr_t)(sW + i * RPP * 128), 16, 0, 0);
         if (AMODE == AMODE_DENSE) {
+            // channel concat [A | A2] folded into the loader: K-steps past k_split read the second tensor (block-uniform choice)
+            const uint16_t* asrc[AP];
+            if (p.A2 != nullptr && k0 >= p.k_split) {
+                const uint16_t* A2g = (const uint16_t*)p.A2 + (k0 - p.k_split) + lsrc * 8;
+#pragma unroll
+                for (int i = 0; i < AP; ++i) asrc[i] = A2g + (size_t)a_y0[i] * p.lda2;
+            } else {
+#pragma unroll
+                for (int i = 0; i < AP; ++i) asrc[i] = aptr[i] + k0;
+            }
             if (p.tile_cfg & 32) {  // set by launch_cfg: non-temporal policy for an activation stream with little reuse
 #pragma unroll
                 for (int i = 0; i < AP; ++i)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + k0), (lptr_t)(sA + i * RPP * 128), 16, 0, 2);
+                    __builtin_amdgcn_global_load_lds((gptr_t)asrc[i], (lptr_t)(sA + i * RPP * 128), 16, 0, 2);
             } else {
 #pragma unroll
-            for (int i = 0; i < AP; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(aptr[i] + k0), (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+                for (int i = 0; i < AP; ++i)
+                    __builtin_amdgcn_global_load_lds((gptr_t)asrc[i], (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         } else if (AMODE == AMODE_CONV3X3) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -253,33 +264,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
     dma_tile(kt0, kt0 & 1);
     __syncthreads();
-    const bool skip_dma = (p.tile_cfg & 16) != 0;  // timing experiment only (results are wrong): no DMA after tile 0
-    if (p.dbg == nullptr) {
-        for (int kt = kt0; kt < nk; ++kt) {
-            const int stage = kt & 1;
-            if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
-            compute(stage);
-            __syncthreads();
-        }
-    } else {  // phase timers (s_memtime, shader cycles) per wave: [dma issue, compute, barrier wait, total], tuning only
-        unsigned long long t_dma = 0, t_cmp = 0, t_bar = 0;
-        const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-        for (int kt = kt0; kt < nk; ++kt) {
-            const int stage = kt & 1;
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            if (kt + 1 < nk && !skip_dma) dma_tile(kt + 1, stage ^ 1);
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-            compute(stage);
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            __syncthreads();
-            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            t_dma += t1 - t0; t_cmp += t2 - t1; t_bar += t3 - t2;
-        }
-        if (lane == 0 && (blockIdx.x % 97) == 0) {
-            unsigned long long* d = (unsigned long long*)p.dbg + ((size_t)(blockIdx.x / 97) * 16 + wave) * 4;
-            d[0] = t_dma; d[1] = t_cmp; d[2] = t_bar; d[3] = __builtin_amdgcn_s_memtime() - t_begin;
-        }
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < nk) dma_tile(kt + 1, stage ^ 1);
+        compute(stage);
+        __syncthreads();
     }
 
     if constexpr (EPI == EPI_LINEAR) {
@@ -289,11 +278,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             q.ldc = p.N;
             q.bias = nullptr; q.rowvec = nullptr; q.res1 = nullptr; q.res2 = nullptr;
             q.alpha = 1.f; q.beta = 0.f;
+            q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr;
             gemm_epilogue<EPI_LINEAR, true, FX, FY, FM, FN>(q, acc, m0, n0, wm, wn, l31, lh);
             return;
         }
     }
-    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh);
+    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn);
 }
 
 // Second pass of a split-K GEMM: out = alpha*(sum_s partial[s] + bias + rowvec + res1) + beta*res2, partials summed in slice order
@@ -329,7 +319,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const VkGemmDesc p, 
         for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
         if (res2) {
             const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
-            v[0] += p.beta * bf16_lo(r.x); v[1] += p.beta * bf16_hi(r.x); v[2] += p.beta * bf16_lo(r.y); v[3] += p.beta * bf16_hi(r.y);
+            float t[4] = {bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)};
+            if (p.rowvec2) {
+                const float4 b = *(const float4*)(p.rowvec2 + (size_t)(m / p.rows_per_vec) * p.ldv + n);
+                t[0] += b.x; t[1] += b.y; t[2] += b.z; t[3] += b.w;
+            }
+            v[0] += p.beta * t[0]; v[1] += p.beta * t[1]; v[2] += p.beta * t[2]; v[3] += p.beta * t[3];
         }
         if (OUT_F32) *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
         else *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + n) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
@@ -360,16 +355,17 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream, int ksplit = 1) {
 // rounding N up to 256 wastes > 10% of the MFMA work), 256x128, 128x128 -- but a variant is only taken if its grid covers the
 // chip (>= 192 workgroups, i.e. at least 3/4 of the CUs with one workgroup each; the 128x128 variant runs two per CU). Small-M problems (deep UNet levels, and every
 // level of a frame-sharded multi-GPU run) therefore fall back to smaller tiles instead of leaving CUs idle.
-template <int AMODE, int EPI, bool OUT_F32>
-int launch(const VkGemmDesc* d, hipStream_t stream) {
-    const int force = d->tile_cfg & 7;  // 0 = auto, 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (tests / tuning)
+struct TileChoice { int cfg, ksplit; };  // cfg: 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320
+inline TileChoice choose_tile(const VkGemmDesc* d) {
+    const int amode = d->amode, epi = d->epi;
+    const int force = d->tile_cfg & 7;  // 0 = auto (tests / tuning force a variant)
     int cfg = force;
-    if (cfg == 4 && AMODE == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
+    if (cfg == 4 && amode == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
     if (cfg == 0) {
         auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
         const int n256 = (d->N + 255) / 256 * 256;
         // GEGLU could run on the 256x320 tile since the fragment-local packing, but measured 2-9 % slower there than on 256x256
-        const bool ok320 = (EPI != EPI_GEGLU) && (AMODE != AMODE_CONV3D) && (d->N % 320 == 0);
+        const bool ok320 = (epi != EPI_GEGLU) && (amode != AMODE_CONV3D) && (d->N % 320 == 0);
         const bool ok256 = n256 * 10 <= d->N * 11;
         const long long need = 192;  // >= 75 % of the 256 CUs in a single round still beats the smaller, less efficient tiles
         if (ok320 && wgs(256, 320) >= need) cfg = 4;
@@ -380,47 +376,82 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
     // Split-K for small-M, deep-K problems (deep UNet levels; every level of a frame-sharded multi-GPU rank): when even the
     // 128-wide tiles would leave the chip under-filled or ragged, run the LARGEST tile over 2..8 K slices instead, so that
     // tiles x slices ~ one full round of CUs; fp32 partials go to the caller's workspace and a finishing pass applies the epilogue.
+    // Not combined with the LayerNorm fold / row-sum emission (their epilogues need the finished accumulator in registers).
     int ksplit = 1;
-    if constexpr (EPI == EPI_LINEAR) {
-        if (force == 0 && d->splitk_ws && cfg != 4 && cfg != 3) {
-            const bool ok320s = (AMODE != AMODE_CONV3D) && (d->N % 320 == 0);
-            const int bn = ok320s ? 320 : 256;
-            const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
-            const int nk = d->K / BK;
-            int s = (int)(256 / tiles);
-            if (s > 8) s = 8;
-            if (s > nk / 8) s = nk / 8;  // at least 8 K-steps per slice
-            if (s >= 2 && tiles * s >= 128 && (long long)s * d->M * d->N * 4 <= d->splitk_ws_bytes) {
-                ksplit = s;
-                cfg = ok320s ? 4 : 3;
-            }
+    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && !d->ln_stats && !d->rowstat_out) {
+        const bool ok320s = (amode != AMODE_CONV3D) && (d->N % 320 == 0);
+        const int bn = ok320s ? 320 : 256;
+        const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
+        const int nk = d->K / BK;
+        int s = (int)(256 / tiles);
+        if (s > 8) s = 8;
+        if (s > nk / 8) s = nk / 8;  // at least 8 K-steps per slice
+        if (s >= 2 && tiles * s >= 128 && (long long)s * d->M * d->N * 4 <= d->splitk_ws_bytes) {
+            ksplit = s;
+            cfg = ok320s ? 4 : 3;
         }
     }
+    return {cfg, ksplit};
+}
+
+// (block-tile width, wave columns) of a variant: the row-sum slabs of rowstat_out are one per (column tile, wave column)
+inline void tile_geometry(int cfg, int& bn, int& wn) {
+    if (cfg == 4) { bn = 320; wn = 2; }
+    else if (cfg == 3) { bn = 256; wn = 4; }
+    else if (cfg == 2) { bn = 128; wn = 4; }
+    else { bn = 128; wn = 2; }
+}
+
+template <int AMODE, int EPI, bool OUT_F32>
+int launch(const VkGemmDesc* d, hipStream_t stream) {
+    const TileChoice t = choose_tile(d);
     if constexpr (AMODE != AMODE_CONV3D) {
         // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
         // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
-        if (cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream, ksplit);
+        if (t.cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream, t.ksplit);
     }
     // 256x256 runs as SIXTEEN waves (4 per SIMD, 64x64 wave tiles, <= 128 VGPRs): same bytes per FLOP as the 8-wave layout, but twice
     // the waves to cover LDS-read latency, DMA issue and the per-K-step barrier (+5-10 % on GEGLU and the N % 320 != 0 projections).
-    if (cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 2>(d, stream, ksplit);
-    if (cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 1>(d, stream);  // 256x128, sixteen 64x32 wave tiles
+    if (t.cfg == 3) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 2>(d, stream, t.ksplit);
+    if (t.cfg == 2) return launch_cfg<AMODE, EPI, OUT_F32, 4, 4, 2, 1>(d, stream);  // 256x128, sixteen 64x32 wave tiles
     return launch_cfg<AMODE, EPI, OUT_F32, 4, 2, 1, 2>(d, stream);  // 128x128 as eight 32x64 wave tiles, two workgroups per CU
 }
 
-}  // namespace
-
-extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+inline int validate(const VkGemmDesc* d) {
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || (d->tile_cfg & 8) || d->tile_cfg > 31) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 7) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;
     if (d->amode == AMODE_TEMPORAL3 && (d->K != 3 * d->Cin || d->T <= 0 || d->S <= 0)) return VK_EINVAL;
     if (d->amode == AMODE_CONV3D && (d->K != 27 * d->Cin || d->T <= 0 || d->H <= 0 || d->Wd <= 0 || d->H >= 4096 || d->Wd >= 4096 ||
                                      (long long)d->M != (long long)(d->M / (d->H * d->Wd)) * d->H * d->Wd)) return VK_EINVAL;
-    if (d->rowvec && d->rows_per_vec <= 0) return VK_EINVAL;
+    if ((d->rowvec || d->rowvec2) && d->rows_per_vec <= 0) return VK_EINVAL;
+    if (d->rowvec2 && (!d->res2 || d->epi != EPI_LINEAR)) return VK_EINVAL;
+    if (d->A2 && (d->amode != AMODE_DENSE || d->k_split <= 0 || d->k_split >= d->K || (d->k_split % BK) != 0 || (d->lda2 % 8) != 0)) return VK_EINVAL;
+    if (d->ln_stats && (d->amode != AMODE_DENSE || d->A2 || !d->ln_colsum || d->ln_parts <= 0 || d->ln_parts > 64 || !(d->ln_eps > 0.f))) return VK_EINVAL;
+    if (d->rowstat_out && (d->epi != EPI_LINEAR || d->out_f32)) return VK_EINVAL;
+    return VK_OK;
+}
+
+}  // namespace
+
+extern "C" int vk_gemm_rowstat_parts(const VkGemmDesc* d) {
+    const int rc = validate(d);
+    if (rc != VK_OK) return rc;
+    if (d->epi != EPI_LINEAR || d->out_f32) return VK_EINVAL;
+    VkGemmDesc q = *d;
+    q.rowstat_out = (float*)1;  // what the launcher will see: never split-K
+    const TileChoice t = choose_tile(&q);
+    int bn, wn;
+    tile_geometry(t.cfg, bn, wn);
+    return ((d->N + bn - 1) / bn) * wn;
+}
+
+extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int rc = validate(d);
+    if (rc != VK_OK) return rc;
     const bool f32 = d->out_f32 != 0;
     switch (d->epi) {
         case EPI_LINEAR:

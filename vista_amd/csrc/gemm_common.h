@@ -25,12 +25,35 @@ __device__ __forceinline__ uint4 widen_pair(uint2 qa, uint2 qb) {
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
 
+// LayerNorm fold (VkGemmDesc.ln_*): statistics of activation row m from the producer's partial sums, summed in slab order.
+struct LnFold {
+    const float2* st;
+    const float* cs;
+    int parts, M;
+    float inv_c, eps;
+    __device__ __forceinline__ explicit LnFold(const VkGemmDesc& p)
+        : st((const float2*)p.ln_stats), cs(p.ln_colsum), parts(p.ln_parts), M(p.M), inv_c(1.f / (float)p.K), eps(p.ln_eps) {}
+    __device__ __forceinline__ void row(int m, float& mu, float& rs) const {
+        float s = 0.f, q = 0.f;
+        for (int i = 0; i < parts; ++i) {
+            const float2 v = st[(size_t)i * M + m];
+            s += v.x;
+            q += v.y;
+        }
+        mu = s * inv_c;
+        rs = rsqrtf(fmaxf(q * inv_c - mu * mu, 0.f) + eps);
+    }
+};
+
 template <int EPI, bool OUT_F32, int FX, int FY, int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh) {
+__device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
+                                              int stat_part = 0) {
     constexpr int MW = FM * 32, NW = FN * 32;
+    const LnFold ln(p);
     if (EPI == EPI_LINEAR) {
         const float* __restrict__ bias = p.bias;
         const float* __restrict__ rowvec = p.rowvec;
+        const float* __restrict__ rowvec2 = p.rowvec2;
         const uint16_t* __restrict__ res1 = (const uint16_t*)p.res1;
         const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
         // 16-byte stores need whole 16-column groups and 16-byte aligned rows (always true for the UNet's shapes)
@@ -38,8 +61,12 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
 #pragma unroll
         for (int fj = 0; fj < FY; ++fj) {
             const int m = m0 + wm * MW + fj * 32 + l31;
-            if (m >= p.M) continue;
+            if (m >= p.M) continue;  // both lanes of a row (l31, l31 + 32) leave together
             const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+            const float* rv2 = rowvec2 ? rowvec2 + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
+            float mu = 0.f, rs = 1.f;
+            if (ln.st) ln.row(m, mu, rs);
+            float ssum = 0.f, qsum = 0.f;  // row sums of the bf16-rounded outputs this lane stores (rowstat_out)
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 uint2 packed[4];
@@ -51,6 +78,11 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
+                    if (ln.st) {
+                        const float4 c = *(const float4*)(ln.cs + n);
+                        v[0] = rs * (v[0] - mu * c.x); v[1] = rs * (v[1] - mu * c.y);
+                        v[2] = rs * (v[2] - mu * c.z); v[3] = rs * (v[3] - mu * c.w);
+                    }
                     if (bias) {
                         const float4 b = *(const float4*)(bias + n);
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -67,14 +99,24 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
                     if (res2) {
                         const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
-                        v[0] += p.beta * bf16_lo(r.x); v[1] += p.beta * bf16_hi(r.x);
-                        v[2] += p.beta * bf16_lo(r.y); v[3] += p.beta * bf16_hi(r.y);
+                        float t[4] = {bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)};
+                        if (rv2) {
+                            const float4 b = *(const float4*)(rv2 + n);
+                            t[0] += b.x; t[1] += b.y; t[2] += b.z; t[3] += b.w;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += p.beta * t[e];
                     }
                     if (OUT_F32) {
                         *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
                         packed[g].x = pack_bf16(v[0], v[1]);
                         packed[g].y = pack_bf16(v[2], v[3]);
+                        if (p.rowstat_out) {
+                            const float a0 = bf16_lo(packed[g].x), a1 = bf16_hi(packed[g].x), a2 = bf16_lo(packed[g].y), a3 = bf16_hi(packed[g].y);
+                            ssum += (a0 + a1) + (a2 + a3);
+                            qsum = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, fmaf(a3, a3, qsum))));
+                        }
                         if (!wide) *(uint2*)((uint16_t*)p.out + (size_t)m * p.ldc + n) = packed[g];
                     }
                 }
@@ -87,6 +129,10 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     }
                 }
             }
+            if (!OUT_F32 && p.rowstat_out) {  // the row's NW columns of this wave tile live in lanes l31 and l31 + 32: fixed-order pair sum
+                const float so = __shfl_xor(ssum, 32, 64), qo = __shfl_xor(qsum, 32, 64);
+                if (lh == 0) ((float2*)p.rowstat_out)[(size_t)stat_part * p.M + m] = make_float2(ssum + so, qsum + qo);
+            }
         }
     } else if (EPI == EPI_GEGLU) {
         // packed weight rows: every 32-row fragment = [16 value rows | 16 gate rows] of the SAME 16 output columns, so the value quad g
@@ -98,6 +144,8 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
         for (int fj = 0; fj < FY; ++fj) {
             const int m = m0 + wm * MW + fj * 32 + l31;
             if (m >= p.M) continue;
+            float mu = 0.f, rs = 1.f;
+            if (ln.st) ln.row(m, mu, rs);
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 const int nfrag = n0 + wn * NW + fi * 32;  // first packed row of the fragment
@@ -111,6 +159,12 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     float a[4], gt[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] = acc[fi][fj][4 * g + e]; gt[e] = acc[fi][fj][4 * (g + 2) + e]; }
+                    if (ln.st) {
+                        const float4 ca = *(const float4*)(ln.cs + np);
+                        const float4 cg = *(const float4*)(ln.cs + np + 16);
+                        a[0] = rs * (a[0] - mu * ca.x); a[1] = rs * (a[1] - mu * ca.y); a[2] = rs * (a[2] - mu * ca.z); a[3] = rs * (a[3] - mu * ca.w);
+                        gt[0] = rs * (gt[0] - mu * cg.x); gt[1] = rs * (gt[1] - mu * cg.y); gt[2] = rs * (gt[2] - mu * cg.z); gt[3] = rs * (gt[3] - mu * cg.w);
+                    }
                     if (bias) {
                         const float4 ba = *(const float4*)(bias + np);
                         const float4 bg = *(const float4*)(bias + np + 16);
@@ -135,13 +189,27 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
             const int n = n0 + wn * NW + fj * 32 + l31;
             if (n >= p.N) continue;
             const float bn = p.bias ? p.bias[n] : 0.f;  // the lane's output channel (VAE AttnBlock v projection carries a bias)
+            const float csn = ln.st ? ln.cs[n] : 0.f;
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 uint2 packed[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    packed[g].x = pack_bf16(acc[fi][fj][4 * g + 0] + bn, acc[fi][fj][4 * g + 1] + bn);
-                    packed[g].y = pack_bf16(acc[fi][fj][4 * g + 2] + bn, acc[fi][fj][4 * g + 3] + bn);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
+                    if (ln.st) {  // the lane's 4 consecutive keys are 4 activation rows: one (mean, rstd) pair each
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            int mr = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh + e;
+                            if (mr >= p.M) mr = p.M - 1;
+                            float mu, rs;
+                            ln.row(mr, mu, rs);
+                            v[e] = rs * (v[e] - mu * csn);
+                        }
+                    }
+                    packed[g].x = pack_bf16(v[0] + bn, v[1] + bn);
+                    packed[g].y = pack_bf16(v[2] + bn, v[3] + bn);
                     if (!wide) {
                         const int m = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh;
                         if (m >= p.M) continue;

@@ -227,7 +227,8 @@ extern "C" int vk_gemm_fp8(const VkGemmDesc* d, const float* a_scale, const floa
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) != 0 || (d->N % 4) != 0 || k_real <= 0 || k_real > d->K || (k_real % 16) != 0 ||
         d->lda < k_real || (d->lda % 16) != 0 || d->amode != AMODE_DENSE || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 7)
         return VK_EINVAL;
-    if (d->rowvec && d->rows_per_vec <= 0) return VK_EINVAL;
+    if ((d->rowvec || d->rowvec2) && d->rows_per_vec <= 0) return VK_EINVAL;
+    if (d->ln_stats || d->rowstat_out || d->A2 || (d->rowvec2 && !d->res2)) return VK_EINVAL;  // bf16-GEMM-only features
     const F8Args q{a_scale, w_scale, k_real};
     const bool f32 = d->out_f32 != 0;
     if (d->epi == EPI_LINEAR) return f32 ? launch<EPI_LINEAR, true>(d, q, stream) : launch<EPI_LINEAR, false>(d, q, stream);

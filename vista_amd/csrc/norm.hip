@@ -19,7 +19,10 @@ constexpr int GN_TOK = 128;  // tokens per workgroup
 
 // stats pass 1: per (image, 128-token chunk) partial (sum, sumsq) of the 32 groups, reduced in a FIXED order
 // (thread partials -> LDS [r][channel] -> per-channel over r -> per-group over channels): bitwise reproducible.
-__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial, int S, int C, int CG, int R, int tok_per_wg) {
+// Two-source form (x2 != NULL): the tensor is the channel concat [x | x2] of C1 + (C - C1) channels (UNet skip concat, never
+// materialised); every thread owns one fixed 16-B channel chunk, so the source choice is a per-thread constant.
+__global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1, float* __restrict__ partial, int S, int C,
+                                int CG, int R, int tok_per_wg) {
     extern __shared__ float lds[];  // [2][R][C]
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
@@ -33,12 +36,14 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restric
         float sm[8], sq[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { sm[e] = 0.f; sq[e] = 0.f; }
-        const uint16_t* p = x + ((size_t)img * S) * C + chunk * 8;
+        const bool second = x2 != nullptr && chunk * 8 >= C1;
+        const int ld = x2 == nullptr ? C : (second ? C - C1 : C1);
+        const uint16_t* p = (second ? x2 + (chunk * 8 - C1) : x + chunk * 8) + ((size_t)img * S) * ld;
         int t = tok0 + r;
         for (; t + 3 * R < tok1; t += 4 * R) {  // 4 independent 16-B loads in flight per thread
             uint4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(p + (size_t)(t + u * R) * C);
+            for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(p + (size_t)(t + u * R) * ld);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float f[8];
@@ -48,7 +53,7 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, float* __restric
             }
         }
         for (; t < tok1; t += R) {
-            const uint4 v = *(const uint4*)(p + (size_t)t * C);
+            const uint4 v = *(const uint4*)(p + (size_t)t * ld);
             float f[8];
             unpack8(v, f);
 #pragma unroll
@@ -112,7 +117,7 @@ __global__ void gn_finalize_level2_kernel(const float* __restrict__ partial, flo
     if (threadIdx.x < 64) sums[(size_t)blockIdx.x * 64 + v] = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
 }
 
-__global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ gamma,
+__global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1, uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ stats, int S, int C, int CG, int R,
                                 int frames_per_group, float inv_cnt, float eps, int do_silu, int tok_per_wg) {
     const int tid = threadIdx.x;
@@ -134,11 +139,14 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
         b[e] = beta[c] - mean * a[e];
     }
     const size_t base = ((size_t)img * S) * C + chunk * 8;
+    const bool second = x2 != nullptr && chunk * 8 >= C1;
+    const int ld = x2 == nullptr ? C : (second ? C - C1 : C1);
+    const uint16_t* xs = (second ? x2 + (chunk * 8 - C1) : x + chunk * 8) + ((size_t)img * S) * ld;
     int t = tok0 + r;
     for (; t + 3 * R < tok1; t += 4 * R) {  // 4 independent 16-B loads in flight per thread
         uint4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(x + base + (size_t)(t + u * R) * C);
+        for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(xs + (size_t)(t + u * R) * ld);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float f[8];
@@ -152,7 +160,7 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
         }
     }
     for (; t < tok1; t += R) {
-        const uint4 v = *(const uint4*)(x + base + (size_t)t * C);
+        const uint4 v = *(const uint4*)(xs + (size_t)t * ld);
         float f[8];
         unpack8(v, f);
 #pragma unroll
@@ -234,6 +242,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     }
 }
 
+// Row sums for a LayerNorm folded into the consumer GEMM: one wave per row, stats[row] = (sum x, sum x^2), lane partials over the
+// row's 16-B chunks then a fixed butterfly -- bitwise reproducible.
+__global__ __launch_bounds__(256) void rowstats_kernel(const uint16_t* __restrict__ x, float2* __restrict__ stats, int rows, int C, long long ldx) {
+    const int lane = threadIdx.x & 63;
+    const int CG = C >> 3;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        float s = 0.f, q = 0.f;
+        for (int ch = lane; ch < CG; ch += 64) {
+            const uint4 v = *(const uint4*)(x + (size_t)row * ldx + ch * 8);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s += f[e]; q = fmaf(f[e], f[e], q); }
+        }
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if (lane == 0) stats[row] = make_float2(s, q);
+    }
+}
+
 }  // namespace
 
 namespace {
@@ -255,14 +283,16 @@ inline bool gn_geom(int n_img, int S, int C, int fpg, GnGeom& g) {
 }
 }  // namespace
 
-extern "C" int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C,
-                                       int32_t frames_per_group, void* stream_) {
+namespace {
+int gn_stats(const void* x, const void* x2, int C1, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group,
+             void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GnGeom g;
     if (!x || !sums || !partial_ws || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
     dim3 grid(g.nchunks, n_img);
     const size_t lds_bytes = (size_t)2 * g.R * C * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, partial_ws, S, C, g.CG, g.R, g.tok);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, partial_ws, S, C, g.CG,
+                       g.R, g.tok);
     VK_CHECK_LAUNCH();
     const int nparts = frames_per_group * g.nchunks;
     if (nparts <= 256) {
@@ -281,15 +311,48 @@ extern "C" int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partia
     return VK_OK;
 }
 
-extern "C" int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img,
-                                       int32_t S, int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream_) {
+int gn_apply(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img, int32_t S,
+             int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     GnGeom g;
     if (!x || !y || !gamma || !beta || !sums || count <= 0.f || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
     const int tok_per_wg = g.tok;
     dim3 grid(g.nchunks, n_img);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (uint16_t*)y, gamma, beta, sums, S, C, g.CG, g.R,
-                       frames_per_group, 1.f / count, eps, silu, tok_per_wg);
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, (uint16_t*)y, gamma, beta, sums,
+                       S, C, g.CG, g.R, frames_per_group, 1.f / count, eps, silu, tok_per_wg);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+}  // namespace
+
+extern "C" int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C,
+                                       int32_t frames_per_group, void* stream_) {
+    return gn_stats(x, nullptr, 0, sums, partial_ws, n_img, S, C, frames_per_group, stream_);
+}
+
+extern "C" int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img,
+                                       int32_t S, int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream_) {
+    return gn_apply(x, nullptr, 0, y, gamma, beta, sums, n_img, S, C, frames_per_group, count, eps, silu, stream_);
+}
+
+extern "C" int vk_groupnorm_silu_cat_bf16(const void* x1, const void* x2, void* y, const float* gamma, const float* beta, float* stats_ws,
+                                          int32_t n_img, int32_t S, int32_t C1, int32_t C2, int32_t frames_per_group, float eps, int32_t silu,
+                                          void* stream_) {
+    if (!x1 || !x2 || !stats_ws || frames_per_group <= 0 || n_img <= 0 || C1 <= 0 || C2 <= 0 || (C1 % 8) != 0 || (C2 % 8) != 0) return VK_EINVAL;
+    const int C = C1 + C2;
+    float* partial = stats_ws + (size_t)(n_img / frames_per_group) * 64;
+    int rc = gn_stats(x1, x2, C1, stats_ws, partial, n_img, S, C, frames_per_group, stream_);
+    if (rc != VK_OK) return rc;
+    const float count = (float)(C / 32) * (float)S * (float)frames_per_group;
+    return gn_apply(x1, x2, C1, y, gamma, beta, stats_ws, n_img, S, C, frames_per_group, count, eps, silu, stream_);
+}
+
+extern "C" int vk_rowstats_bf16(const void* x, float* stats, int32_t rows, int32_t C, int64_t ldx, void* stream_) {
+    if (!x || !stats || rows <= 0 || C <= 0 || (C % 8) != 0 || C > 1536 || ldx < C || (ldx % 8) != 0) return VK_EINVAL;
+    long long want = ((long long)rows + 3) / 4;
+    const long long cap = 256LL * 16;
+    hipLaunchKernelGGL(rowstats_kernel, dim3((int)(want < cap ? want : cap)), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)x, (float2*)stats,
+                       rows, C, (long long)ldx);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }

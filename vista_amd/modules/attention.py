@@ -31,29 +31,37 @@ def default(val, d):
 
 
 class Packable:
-    """Lazy bf16 weight packing (ops.pack_*), rebuilt when parameters move device or are reloaded."""
+    """Lazy bf16 weight packing (ops.pack_*). The pack is keyed on the device, dtype and in-place version counters of the
+    parameters it was built from, so it is rebuilt after `.cuda()`, after ANY load_state_dict (also one issued on a parent
+    container, which never reaches the children's own load_state_dict) and after in-place updates (EMA swap, `p.data.copy_`)."""
     _pk = None
-    _pk_dev = None
+    _pk_key = None
+    _pk_params = None
 
-    _pk_param = None
+    def _pack_params(self):
+        """Parameters the pack depends on (default: every parameter under this module)."""
+        return list(self.parameters())
 
     def packed(self):
-        p = self._pk_param
-        if p is None:  # one Parameter kept as the device probe: .cuda()/.to() swap its .data in place, so its .device stays current
-            p = next(self.parameters())
-            object.__setattr__(self, "_pk_param", p)  # plain attribute: nn.Module.__setattr__ would register it as a parameter
-        dev = p.device
+        ps = self._pk_params
+        if ps is None:
+            ps = self._pack_params()
+            object.__setattr__(self, "_pk_params", ps)  # plain attribute: nn.Module.__setattr__ would try to register it
+        p0 = ps[0]
+        dev = p0.device
         if dev.type != "cuda":
             raise ops._lib.VistaHipError(f"{self.__class__.__name__}: parameters are on {dev}; move the model to the MI355X "
                                          "(.cuda()) -- vista_amd has no CPU path")
-        if self._pk is None or self._pk_dev != dev:
+        key = (dev, p0.dtype, *[p._version for p in ps])
+        if self._pk is None or self._pk_key != key:
             with torch.no_grad():
                 self._pk = self._pack(dev)
-            self._pk_dev = dev
+            self._pk_key = key
         return self._pk
 
     def invalidate_packed(self):
         self._pk = None
+        object.__setattr__(self, "_pk_params", None)  # a replaced nn.Parameter object is picked up on the next pack
 
 
 class GEGLU(nn.Module):
@@ -88,8 +96,13 @@ class FeedForward(nn.Module, Packable):
             pk["out8"] = ops.pack_linear_fp8(self.net[2].weight, self.net[2].bias, dev)
         return pk
 
+    def pack_in_folded(self, norm, dev):
+        """GEGLU in-projection with the preceding LayerNorm `norm` folded in (the owner block packs it: it owns the norm)."""
+        return ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev, ln=norm)
+
     def forward(self, y, **epilogue):
-        """y: LN output (M, dim). Returns net(y) fused with the residual / blend epilogue given by the caller."""
+        """y: LN output (M, dim). Returns net(y) fused with the residual / blend epilogue given by the caller (unfolded form: used
+        by the fp8 experiment and by callers that already hold a normalised input)."""
         pk = self.packed()
         if not FP8["feedforward"]:
             return ops.linear(ops.linear(y, pk["in"]), pk["out"], **epilogue)
@@ -100,6 +113,15 @@ class FeedForward(nn.Module, Packable):
         h = ops.linear_fp8(yq, ys, pk["in8"])
         hq, hs = ops.quantize_rows_fp8(h)
         return ops.linear_fp8(hq, hs, pk["out8"], **epilogue)
+
+    def forward_folded(self, x, stats, pw_in, norm, **epilogue):
+        """net(LayerNorm(x)) with the LayerNorm folded into the GEGLU GEMM: x (M, dim) is the un-normalised residual stream,
+        `stats` its RowStats, `pw_in` = pack_in_folded(norm). No normalised tensor is ever written (attention.py:524)."""
+        if FP8["feedforward"]:  # config-5 experiment keeps the explicit LayerNorm (it quantises the normalised rows)
+            emit = epilogue.pop("emit_stats", False)
+            out = self.forward(ops.layernorm(x, norm.weight, norm.bias, norm.eps), **epilogue)
+            return (out, ops.rowstats(out)) if emit else out
+        return ops.linear(ops.linear(x, pw_in, ln=stats), self.packed()["out"], **epilogue)
 
 
 class MemoryEfficientCrossAttention(nn.Module, Packable):
@@ -134,12 +156,7 @@ class MemoryEfficientCrossAttention(nn.Module, Packable):
 
     def _pack(self, dev):
         pk = {"out": ops.pack_linear(self.to_out[0].weight, self.to_out[0].bias, dev)}
-        if self.is_self and getattr(self, "temporal", False):  # per-pixel attention over frames: one fused q|k|v GEMM
-            pk["qkv"] = ops.pack_linear_cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dev)
-        elif self.is_self:  # spatial: fused q|k GEMM + a transposed-output V^T GEMM
-            pk["qk"] = ops.pack_linear_cat([self.to_q.weight, self.to_k.weight], dev)
-            pk["v"] = ops.pack_linear(self.to_v.weight, None, dev)
-        else:
+        if not self.is_self:
             ws = [self.to_v.weight]
             if self.action_control:
                 ws.append(self.v_adapter_action_control.weight)
@@ -177,18 +194,29 @@ class BasicTransformerBlock(nn.Module, Packable):
         self.use_checkpoint = use_checkpoint
         self.n_heads, self.dim = n_heads, dim
 
-    def forward(self, x, context, n_img, S):
-        """x: (n_img*S, dim) bf16 tokens; context: (n_img, ctx_width) bf16 (one context token per image)."""
+    def _pack(self, dev):
+        # LayerNorms folded into the GEMMs that consume them (norm1 -> q|k and v^T projections, norm3 -> GEGLU): the block owns the
+        # norms, so it packs those weights; attn1 / ff keep their own out-projections. norm2 only feeds the 1-token cross-attention's
+        # query, which cannot influence the output (softmax over one key == 1).
+        a = self.attn1
+        return {"qk": ops.pack_linear_cat([a.to_q.weight, a.to_k.weight], dev, ln=self.norm1),
+                "v": ops.pack_linear(a.to_v.weight, None, dev, ln=self.norm1),
+                "ff_in": self.ff.pack_in_folded(self.norm3, dev)}
+
+    def forward(self, x, stats, context, n_img, S, out_rowvec=None, emit_stats=True):
+        """x: (n_img*S, dim) bf16 tokens with their RowStats; context: (n_img, ctx_width) bf16 (one context token per image).
+        out_rowvec: optional (n_img, dim) f32 added per image to the block output (the frame-position embedding of
+        video_attention.py:283-284, so the temporal block's input leaves this block's last epilogue). Returns (out, RowStats)."""
+        pk = self.packed()
         a1 = self.attn1.packed()
         C = self.dim
-        y = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qk = ops.linear(y, a1["qk"])
-        vt = ops.linear_vt(y, a1["v"], S)
+        qk = ops.linear(x, pk["qk"], ln=stats)            # LayerNorm(norm1) folded: x is read, never a normalised copy
+        vt = ops.linear_vt(x, pk["v"], S, ln=stats)
         att = ops.attn_spatial(qk[:, :C], qk[:, C:], vt, n_img, self.n_heads, S, self.attn1.dim_head ** -0.5)
         cv = self.attn2.context_vector(context)  # attn2(norm2(x), context): constant over the image's tokens
-        x = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=S)
-        y = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
-        return self.ff(y, res1=x)
+        x, st = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=S, emit_stats=True)
+        r = self.ff.forward_folded(x, st, pk["ff_in"], self.norm3, res1=x, rowvec=out_rowvec, rows_per_vec=S, emit_stats=emit_stats)
+        return r if emit_stats else (r, None)
 
 
 class SpatialTransformer(nn.Module, Packable):

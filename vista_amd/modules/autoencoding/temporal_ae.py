@@ -41,11 +41,13 @@ class VideoResBlock(ResnetBlock):
         self._alpha = None
 
     def get_alpha(self):
-        """temporal_ae.py:47-53 as a host float (one D2H read per weight load, none per decode)."""
-        if self._alpha is None:
-            m = float(self.mix_factor.detach().float().cpu().item())
-            self._alpha = m if self.merge_strategy == "fixed" else 1.0 / (1.0 + math.exp(-m))
-        return self._alpha
+        """temporal_ae.py:47-53 as a host float (one D2H read per weight load, none per decode); re-read when mix_factor changes."""
+        mf = self.mix_factor
+        key = (mf.device, mf._version)
+        if self._alpha is None or self._alpha[0] != key:
+            m = float(mf.detach().float().cpu().item())
+            self._alpha = (key, m if self.merge_strategy == "fixed" else 1.0 / (1.0 + math.exp(-m)))
+        return self._alpha[1]
 
     def forward(self, x, temb, H, W, skip_video=False, timesteps=None):
         if timesteps is None:

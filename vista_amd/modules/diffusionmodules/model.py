@@ -193,6 +193,9 @@ class Decoder(nn.Module, Packable):
     def get_last_layer(self, **kwargs):
         return self.conv_out.weight
 
+    def _pack_params(self):  # only what _pack reads (the children pack themselves)
+        return [self.conv_in.weight, self.conv_in.bias]
+
     def _pack(self, dev):
         return {"conv_in": ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias, cin_pad=CIN_PAD, device=dev)}
 
@@ -261,6 +264,9 @@ class Encoder(nn.Module, Packable):
         self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
         self.norm_out = Normalize(block_in)
         self.conv_out = _Conv2dOut(block_in, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1, padding=1)
+
+    def _pack_params(self):  # only what _pack reads (the children pack themselves)
+        return [self.conv_in.weight, self.conv_in.bias]
 
     def _pack(self, dev):
         return {"conv_in": ops.pack_conv3x3(self.conv_in.weight, self.conv_in.bias, cin_pad=CIN_PAD, device=dev)}

@@ -124,12 +124,19 @@ class ResBlock(TimestepBlock, Packable):
         return pk
 
     def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, shard=None, T_global=None):
-        """x (n_img, S, C) bf16; emb_silu (n_img, emb_channels) bf16 = silu(emb).
+        """x (n_img, S, C) bf16, or a pair (h, skip) standing for their channel concat (the `torch.cat([h, hs.pop()], dim=1)` of
+        the UNet's output blocks, video_model.py:493, read in place by the norm and the 1x1 skip conv -- never materialised);
+        emb_silu (n_img, emb_channels) bf16 = silu(emb).
         dims=2: returns skip(x) + h.  dims=3 (time_stack): statistics/conv span the T frames of each clip and the result is
         blend + out_alpha*(conv2 + bias) with blend = x, i.e. AlphaBlender(x_spatial=x, x_temporal=x+h) folded in.
         Multi-GPU (`shard`): x holds T = t_local frames of a T_global-frame clip; the norms all-reduce their partial sums and
         the convs read the neighbour ranks' boundary frames (halo exchange)."""
         pk = self.packed()
+        xb = None
+        if isinstance(x, tuple):
+            x, xb = x
+            if self.dims != 2 or "skip" not in pk:
+                raise ValueError("a concatenated input needs the 2-D ResBlock with a 1x1 skip convolution")
         n_img, S, _ = x.shape
         gn1, gn2 = self.in_layers[0], self.out_layers[0]
         fpg = 1 if self.dims == 2 else T
@@ -152,11 +159,11 @@ class ResBlock(TimestepBlock, Packable):
 
         def halo(t):
             return shard.halo_exchange(t) if (shard is not None and self.dims == 3) else (None, None)
-        h = gnorm(x, gn1)
+        h = gnorm(x, gn1) if xb is None else ops.groupnorm_cat(x, xb, gn1.weight, gn1.bias, gn1.eps, silu=True)
         if self.dims == 2:
             h, _, _ = ops.conv3x3(h, pk["conv1"], n_img, H, W, rowvec=emb_out)
             h = ops.groupnorm(h, gn2.weight, gn2.bias, gn2.eps, silu=True)
-            skip = x if "skip" not in pk else ops.linear(x, pk["skip"])
+            skip = x if "skip" not in pk else ops.linear(x, pk["skip"], x2=xb)
             out, _, _ = ops.conv3x3(h, pk["conv2"], n_img, H, W, res1=skip)
             return out
         if self.full3d:  # 3x3x3 time_stack (VAE decoder with video_kernel_size=3); single-GPU only

@@ -87,7 +87,7 @@ class EulerEDMSampler(SingleStepDiffusionSampler):
             cond_mask = torch.zeros(x.shape[0], device=x.device)
         maskf = cond_mask.float().contiguous()
         if isinstance(denoiser, FusedDenoiser) and not isinstance(self.guider, IdentityGuider) and self.s_churn == 0.0 \
-                and x.dim() == 4 and x.shape[1] == 4:
+                and self._fused_layout_ok(denoiser, x, cond, uc):
             return self._sample_fused(denoiser, x, cond, uc, cond_frame, maskf, replace, sig)
         n = x.shape[0]
         xw = x.float()
@@ -103,6 +103,20 @@ class EulerEDMSampler(SingleStepDiffusionSampler):
         return xw.to(x.dtype)
 
     # ---- fused path ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _fused_layout_ok(fd, x, cond, uc):
+        """The fused kernels hard-code Vista's layout: a 4-channel latent, a 4-channel `concat` conditioning of the same H x W
+        (per frame or per clip), `crossattn` / `vector` present and an 8-channel UNet input. Anything else takes the generic path."""
+        if x.dim() != 4 or x.shape[1] != 4 or getattr(fd.network.diffusion_model, "in_channels", None) != 8:
+            return False
+        for d in (cond, uc):
+            if d is None or any(k not in d for k in ("concat", "crossattn", "vector")):
+                return False
+            c = d["concat"]
+            if c.dim() != 4 or tuple(c.shape[1:]) != tuple(x.shape[1:]):
+                return False
+        return True
+
     def _sample_fused(self, fd, x, cond, uc, cond_frame, maskf, replace, sig):
         """`self.shard` (a vista_amd.parallel.FrameShard, set by the caller on every rank) turns on frame sharding: every
         rank passes the same full-window tensors, works on its own frames and returns the gathered full result."""

@@ -22,6 +22,31 @@ from .util import AlphaBlender, SiLU, conv_nd, linear, mlp_f32, normalization, t
 CIN_PAD = 64  # the 8 input channels are zero-padded to one 64-wide K-step of the implicit GEMM
 
 
+class _ThreadTable:
+    """Per-thread slot for the batched emb_layers projection of the forward in flight (the multi-rank tests drive one model from
+    several threads). Unlike threading.local it survives copy.deepcopy / pickling of the module that owns it (a fresh, empty table)."""
+
+    def __init__(self):
+        self._slots = {}
+
+    @property
+    def table(self):
+        return self._slots.get(threading.get_ident())
+
+    @table.setter
+    def table(self, value):
+        if value is None:
+            self._slots.pop(threading.get_ident(), None)
+        else:
+            self._slots[threading.get_ident()] = value
+
+    def __deepcopy__(self, memo):
+        return _ThreadTable()
+
+    def __reduce__(self):
+        return (_ThreadTable, ())
+
+
 class VideoResBlock(ResBlock):
     """video_model.py:9-75: 2-D ResBlock, then the (3,1,1) temporal ResBlock over `b c t h w`, blended by AlphaBlender."""
 
@@ -34,21 +59,23 @@ class VideoResBlock(ResBlock):
                                    use_conv=False, up=False, down=False, kernel_size=video_kernel_size, use_checkpoint=use_checkpoint,
                                    exchange_temb_dims=True, causal=False)
         self.time_mixer = AlphaBlender(alpha=merge_factor, merge_strategy=merge_strategy, rearrange_pattern="b t -> b 1 t 1 1")
-        self._alpha = None
 
-    def invalidate_packed(self):
-        super().invalidate_packed()
-        self._alpha = None
+    def _pack_params(self):  # the spatial ResBlock's own tensors + the blend factor; time_stack packs itself
+        return [p for n, p in self.named_parameters() if not n.startswith("time_stack.")]
+
+    def _pack(self, dev):
+        pk = super()._pack(dev)
+        pk["alpha"] = self.time_mixer.alpha_value()
+        return pk
 
     def forward(self, x, emb_silu, num_frames, H, W, shard=None, full=None):
         x = super().forward(x, emb_silu, H, W)
-        if self._alpha is None:
-            self._alpha = self.time_mixer.alpha_value()
+        alpha = self.packed()["alpha"]
         # alpha*x + (1-alpha)*(x + h_t) == x + (1-alpha)*h_t, fused into the last temporal conv's epilogue
         if shard is None:
-            return self.time_stack(x, emb_silu, H, W, T=num_frames, out_alpha=1.0 - self._alpha)
+            return self.time_stack(x, emb_silu, H, W, T=num_frames, out_alpha=1.0 - alpha)
         # frame-sharded: the temporal ResBlock keeps this rank's frames (halo exchange + stats all-reduce inside)
-        return self.time_stack(x, emb_silu, H, W, T=shard.t_local, out_alpha=1.0 - self._alpha, shard=shard, T_global=num_frames)
+        return self.time_stack(x, emb_silu, H, W, T=shard.t_local, out_alpha=1.0 - alpha, shard=shard, T_global=num_frames)
 
 
 class VideoUNet(nn.Module, Packable):
@@ -198,7 +225,7 @@ class VideoUNet(nn.Module, Packable):
         # Every ResBlock (spatial and time_stack) projects the SAME silu(emb) through its own emb_layers Linear: 44 launches of a
         # 7..50-row GEMM per forward. forward_tokens runs them as ONE GEMM over the row-concatenated weights and hands each block
         # its column slice through this thread-local table (thread-local: the multi-rank tests drive one model from several threads).
-        self._emb_tls = threading.local()
+        self._emb_tls = _ThreadTable()
         off = 0
         self._emb_blocks = []
         for m in self.modules():
@@ -208,15 +235,18 @@ class VideoUNet(nn.Module, Packable):
                 off += m.out_channels
 
     # ---- weights ----
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        r = super().load_state_dict(state_dict, strict=strict, **kw)
-        self.invalidate_all_packed()
-        return r
-
+    # No load_state_dict override: every Packable keys its packed weights on its parameters' version counters, so ANY load
+    # (this module's, a parent container's, an in-place EMA swap) is picked up at the next forward.
     def invalidate_all_packed(self):
         for m in self.modules():
             if isinstance(m, Packable):
                 m.invalidate_packed()
+
+    def _pack_params(self):  # only what _pack reads (the children pack themselves)
+        ps = [p for seq in (self.time_embed, self.cond_time_stack_embed, self.label_emb, self.out) for p in seq.parameters()]
+        for m in self._emb_blocks:
+            ps += list(m.emb_layers.parameters())
+        return ps
 
     def _pack(self, dev):
         def mlp(seq):
@@ -293,8 +323,9 @@ class VideoUNet(nn.Module, Packable):
                 hs.append(h)
             h, H, W = self.middle_block(h, emb_silu, context=ctx, H=H, W=W, **kw)
             for module in self.output_blocks:
-                h = ops.concat_channels(h, hs.pop())
-                h, H, W = module(h, emb_silu, context=ctx, H=H, W=W, **kw)
+                # `torch.cat([h, hs.pop()], dim=1)` (video_model.py:493) is never materialised: the ResBlock's first norm and its
+                # 1x1 skip conv read the two tensors in place
+                h, H, W = module((h, hs.pop()), emb_silu, context=ctx, H=H, W=W, **kw)
         finally:
             self._emb_tls.table = None
         gn = self.out[0]

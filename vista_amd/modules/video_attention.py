@@ -5,11 +5,15 @@ LayerNorm, the GEGLU feed-forwards and the q/k/v/out projections are per-token, 
 unchanged, and only the 25x25 attention core gathers across frames (vk_attn_temporal_bf16 reads rows with stride S).
 
   VideoTransformerBlock._forward (video_attention.py:111-141), per pixel over T frames:
-      x = ff_in(norm_in(x)) + x        x_mix = x + frame-pos-emb is fused into the norm_in LayerNorm kernel
+      x = ff_in(norm_in(x)) + x        x_mix = x + frame-pos-emb leaves the spatial block's last GEMM epilogue
       x = attn1(norm1(x)) + x          fused q|k|v GEMM -> temporal attention -> out GEMM (+res)
       x = attn2(norm2(x), ctx) + x     one-token context (first frame's, video_attention.py:252-257): per-clip constant
                                        vector, added as a row vector in the attn1 out-projection epilogue
       x = ff(norm3(x)) + x             the AlphaBlender mix with the spatial branch is fused into this GEMM's epilogue
+
+Every LayerNorm is folded into the GEMM that consumes it (include/vista_hip.h, VkGemmDesc.ln_*): the producing GEMM's epilogue
+emits per-row (sum, sum of squares) partials of its bf16 output and the consumer applies rstd*(acc - mean*colsum) in its own
+epilogue, so no normalised tensor is written or read (7 full HBM passes per block pair less).
 """
 import torch.nn as nn
 
@@ -54,28 +58,43 @@ class VideoTransformerBlock(nn.Module, Packable):
         self.use_checkpoint = use_checkpoint
         self.n_heads, self.dim = n_heads, dim
 
-    def forward(self, x, emb_rows, clip_context, B, T, S, blend_with, alpha):
-        """x: ((b t) s, dim) bf16 = the spatial branch output; emb_rows: (b*t, dim) f32 frame-position embedding;
-        clip_context: (b, ctx_width) bf16 (context of each clip's first frame). Returns
-        alpha*blend_with + (1-alpha)*temporal_branch  (AlphaBlender, util.py:311-318)."""
+    def _pack(self, dev):
+        # the four LayerNorms of the block, folded into the GEMMs that consume them (this block owns the norms)
+        a = self.attn1
+        return {"ffin_in": self.ff_in.pack_in_folded(self.norm_in, dev),
+                "qkv": ops.pack_linear_cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dev, ln=self.norm1),
+                "ff_in": self.ff.pack_in_folded(self.norm3, dev)}
+
+    def forward(self, x_mix, stats, emb_rows, clip_context, B, T, S, alpha, emit_stats=False):
+        """x_mix: ((b t) s, dim) bf16 = spatial branch output + frame-position embedding (video_attention.py:283-284) with its
+        RowStats; emb_rows: (b*t, dim) f32 that embedding; clip_context: (b, ctx_width) bf16 (context of each clip's first frame).
+        Returns alpha*x_spatial + (1-alpha)*temporal_branch (AlphaBlender, util.py:311-318) with x_spatial = x_mix - emb recovered
+        in the last epilogue (res2 + rowvec2), so the un-embedded tensor is never stored."""
         assert self.timesteps is None or self.timesteps == T
-        if self.ff_in:
-            y, x = ops.layernorm(x, self.norm_in.weight, self.norm_in.bias, self.norm_in.eps, addvec=emb_rows, rows_per_vec=S,
-                                 want_sum=True)  # x <- x + emb (bf16), y = LN(x)
-            x = self.ff_in(y, res1=x)
-        else:
+        if not self.ff_in:
             raise NotImplementedError("extra_ff_mix_layer=False is not the Vista configuration")
+        pk = self.packed()
         a1 = self.attn1.packed()
-        y = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qkv = ops.linear(y, a1["qkv"])
+        x, st = self.ff_in.forward_folded(x_mix, stats, pk["ffin_in"], self.norm_in, res1=x_mix, emit_stats=True)
+        qkv = ops.linear(x, pk["qkv"], ln=st)
         att = ops.attn_temporal(qkv, B, T, S, self.n_heads, self.attn1.dim_head ** -0.5)
         if self.has_cross:
             cv = self.attn2.context_vector(clip_context)  # (b, dim) f32, constant over the clip's frames and pixels
-            x = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=T * S)
+            x, st = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=T * S, emit_stats=True)
         else:
-            x = ops.linear(att, a1["out"], res1=x)
-        y = ops.layernorm(x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
-        return self.ff(y, res1=x, alpha=1.0 - alpha, res2=blend_with, beta=alpha)
+            x, st = ops.linear(att, a1["out"], res1=x, emit_stats=True)
+        r = self.ff.forward_folded(x, st, pk["ff_in"], self.norm3, res1=x, alpha=1.0 - alpha, res2=x_mix, rowvec2=emb_rows.neg_rows,
+                                   beta=alpha, rows_per_vec=S, emit_stats=emit_stats)
+        return r if emit_stats else (r, None)
+
+
+class _EmbRows:
+    """Frame-position embedding rows (b*t, C) f32 and their negation (the blend epilogue subtracts them again)."""
+
+    __slots__ = ("rows", "neg_rows")
+
+    def __init__(self, rows):
+        self.rows, self.neg_rows = rows, rows.neg()
 
 
 class SpatialVideoTransformer(SpatialTransformer):
@@ -124,20 +143,24 @@ class SpatialVideoTransformer(SpatialTransformer):
         n_img, S, C = x.shape
         x_in = x
         h = ops.groupnorm(x, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
-        h = ops.linear(h, pk["proj_in"])                                           # (n_img*S, C)
-        emb = mlp_f32(timestep_embedding(frame_idx, self.in_channels, self.max_time_embed_period), pk["tpe0"], pk["tpe2"])
+        h, st = ops.linear(h, pk["proj_in"], emit_stats=True)                      # (n_img*S, C) + row sums for norm1
+        emb = _EmbRows(mlp_f32(timestep_embedding(frame_idx, self.in_channels, self.max_time_embed_period), pk["tpe0"], pk["tpe2"]))
         ctx_full = context if shard is None else full["ctx"]
         B = ctx_full.shape[0] // T
         clip_context = ctx_full.view(B, T, -1)[:, 0]                               # context[::T] (first frame of each clip)
-        for block, mix_block in zip(self.transformer_blocks, self.time_stack):
-            h = block(h, context, n_img, S)
+        emb_local = emb.rows if shard is None else shard.take_local_rows(emb.rows)  # spatial half sees this rank's frames only
+        last = len(self.transformer_blocks) - 1
+        for i, (block, mix_block) in enumerate(zip(self.transformer_blocks, self.time_stack)):
+            # spatial block; its last epilogue adds the frame-position embedding: h = x_spatial + emb
+            h, st = block(h, st, context, n_img, S, out_rowvec=emb_local, emit_stats=shard is None)
             if shard is None:
-                h = mix_block(h, emb, clip_context, B, T, S, blend_with=h, alpha=pk["alpha"])
+                h, st = mix_block(h, st, emb, clip_context, B, T, S, alpha=pk["alpha"], emit_stats=i != last)
             else:
                 hp = shard.to_pixels(h.view(n_img, S, C))                          # (B*T, S_r, C)
                 s_r = hp.shape[1]
                 hp = hp.view(-1, C)
-                hp = mix_block(hp, emb, clip_context, B, T, s_r, blend_with=hp, alpha=pk["alpha"])
+                hp, _ = mix_block(hp, ops.rowstats(hp), emb, clip_context, B, T, s_r, alpha=pk["alpha"])
                 h = shard.to_frames(hp.view(B * T, s_r, C), S).view(-1, C)
+                st = ops.rowstats(h) if i != last else None
         out = ops.linear(h, pk["proj_out"], res1=x_in)
         return out.view(n_img, S, C)

@@ -51,30 +51,50 @@ def ceil_to(x, m):
 
 # ---------------------------------------------------------------------------------------------- weight packing
 class PackedWeight:
-    """bf16 [ceil256(N)][K] weight (K contiguous) + f32 bias, laid out for vk_gemm_bf16."""
+    """bf16 [ceil256(N)][K] weight (K contiguous) + f32 bias, laid out for vk_gemm_bf16. `colsum` (f32 [Np]) marks a weight with a
+    LayerNorm folded in (pack_*_ln): wt = gamma (.) W, bias = W beta + b, colsum = row sums of the bf16-rounded wt."""
 
-    __slots__ = ("wt", "bias", "N", "K", "geglu")
+    __slots__ = ("wt", "bias", "N", "K", "geglu", "colsum", "ln_eps")
 
-    def __init__(self, wt, bias, N, K, geglu=False):
-        self.wt, self.bias, self.N, self.K, self.geglu = wt, bias, N, K, geglu
+    def __init__(self, wt, bias, N, K, geglu=False, colsum=None, ln_eps=0.0):
+        self.wt, self.bias, self.N, self.K, self.geglu, self.colsum, self.ln_eps = wt, bias, N, K, geglu, colsum, ln_eps
 
 
-def _finish_pack(w2d, bias, device, geglu=False):
+def _finish_pack(w2d, bias, device, geglu=False, ln=None):
+    """ln = (gamma, beta, eps): fold `LayerNorm(x) @ W^T + b` into the GEMM (include/vista_hip.h, VkGemmDesc.ln_*):
+    LN(x) W^T + b = rstd * (x W'^T - mean * s) + t with W' = gamma (.) W, s_n = sum_k bf16(W')[n][k], t = W beta + b."""
     N, K = w2d.shape
     Kp = ceil_to(K, 64)
     Np = max(ceil_to(N, 256), ceil_to(N, 320))  # readable by every block-tile variant (128/256/320-wide) without bounds checks
+    colsum, eps = None, 0.0
+    if ln is not None:
+        gamma, beta, eps = ln
+        if Kp != K:
+            raise ValueError("LayerNorm fold needs K % 64 == 0")
+        gamma, beta = gamma.detach().float().to(w2d.device), beta.detach().float().to(w2d.device)
+        t = w2d @ beta
+        bias = t if bias is None else bias.to(w2d.device) + t
+        w2d = w2d * gamma[None, :]
     wt = torch.zeros((Np, Kp), dtype=BF16, device=device)
     wt[:N, :K] = w2d.to(device=device, dtype=BF16)
+    if ln is not None:
+        colsum = wt.float().sum(dim=1).contiguous()  # of the ROUNDED weights: the mean term then cancels exactly in the epilogue
     b = None
     if bias is not None:
         b = torch.zeros((Np,), dtype=F32, device=device)
         b[:N] = bias.to(device=device, dtype=F32)
-    return PackedWeight(wt, b, ceil_to(N, 4), Kp, geglu)  # N % 4 == 0 for the 4-column epilogue quads; the extra rows/bias are zero
+    return PackedWeight(wt, b, ceil_to(N, 4), Kp, geglu, colsum, float(eps))  # N % 4 == 0 for the 4-column epilogue quads; the extra rows/bias are zero
 
 
-def pack_linear(weight, bias=None, device="cuda"):
-    """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1])."""
-    return _finish_pack(weight.detach().reshape(weight.shape[0], -1).float(), None if bias is None else bias.detach().float(), device)
+def _ln_tuple(norm):
+    """(gamma, beta, eps) of a LayerNorm parameter container."""
+    return (norm.weight, norm.bias, norm.eps)
+
+
+def pack_linear(weight, bias=None, device="cuda", ln=None):
+    """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1]). ln: LayerNorm container applied to the input (folded)."""
+    return _finish_pack(weight.detach().reshape(weight.shape[0], -1).float(), None if bias is None else bias.detach().float(), device,
+                        ln=None if ln is None else _ln_tuple(ln))
 
 
 def pack_rows_as_weight(t, N, K):
@@ -84,9 +104,9 @@ def pack_rows_as_weight(t, N, K):
     return PackedWeight(t, None, N, K)
 
 
-def pack_linear_cat(weights, device="cuda"):
+def pack_linear_cat(weights, device="cuda", ln=None):
     """Several bias-free Linear weights sharing the input, concatenated along N (fused q|k or q|k|v projection)."""
-    return _finish_pack(torch.cat([w.detach().float() for w in weights], 0), None, device)
+    return _finish_pack(torch.cat([w.detach().float() for w in weights], 0), None, device, ln=None if ln is None else _ln_tuple(ln))
 
 
 def geglu_perm(nout):
@@ -98,12 +118,12 @@ def geglu_perm(nout):
     return torch.stack([idx, idx + nout], 1).reshape(-1)  # [v-block0, g-block0, v-block1, g-block1, ...]
 
 
-def pack_geglu(weight, bias, device="cuda"):
+def pack_geglu(weight, bias, device="cuda", ln=None):
     """GEGLU.proj weight [2*Nout][K]: value rows then gate rows (attention.py:85-92), packed in `geglu_perm` order."""
     w = weight.detach().float()
     b = bias.detach().float()
-    perm = geglu_perm(w.shape[0] // 2)
-    return _finish_pack(w[perm], b[perm], device, geglu=True)
+    perm = geglu_perm(w.shape[0] // 2).to(w.device)
+    return _finish_pack(w[perm], b[perm], device, geglu=True, ln=None if ln is None else _ln_tuple(ln))
 
 
 def pack_conv3x3(weight, bias=None, cin_pad=None, device="cuda"):
@@ -129,38 +149,62 @@ def pack_conv_t3(weight, bias=None, device="cuda", cin_pad=None):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM family
-TILE_CFG = 0  # 0 = auto; tests force 1/2/3 to cover every block-tile variant
-TILE_FLAGS = int(os.environ.get("VISTA_TILE_FLAGS", "0"))  # tuning only: 16 = no-DMA timing experiment (results invalid)
+TILE_CFG = 0  # 0 = auto; tests force 1/2/3/4 to cover every block-tile variant
 
 
-SPLITK_WS_BYTES = int(os.environ.get("VISTA_SPLITK_WS_MB", "160")) << 20  # fp32 split-K workspace per device (0 disables split-K)
+SPLITK_WS_BYTES = int(os.environ.get("VISTA_SPLITK_WS_MB", "160")) << 20  # fp32 split-K workspace per (device, stream) (0 disables split-K)
 _SPLITK_WS = {}
 
 
-def _splitk_workspace():
-    """One workspace per device, reused by every GEMM (all launches go to torch's current stream, hence are ordered)."""
-    dev = torch._C._cuda_getDevice()
-    ws = _SPLITK_WS.get(dev)
+def _splitk_workspace(stream):
+    """One workspace per (device, stream): launches on one stream are ordered, so they may share it; GEMMs in flight on
+    different streams must not (include/vista_hip.h, VkGemmDesc.splitk_ws)."""
+    key = (torch._C._cuda_getDevice(), stream.value)
+    ws = _SPLITK_WS.get(key)
     if ws is None:
-        ws = _SPLITK_WS[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{dev}")
+        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{key[0]}")
     return ws
 
 
-GEMM_DBG = None  # tuning only: a u64 CUDA tensor receiving per-wave phase timers of sampled workgroups
+class RowStats:
+    """Per-row (sum, sum of squares) partials of an activation tensor, f32 [parts][M][2] (include/vista_hip.h, VkGemmDesc.ln_stats):
+    written by the producing GEMM's epilogue (linear(..., emit_stats=True)) or by rowstats(); consumed by a GEMM with a folded LayerNorm."""
+
+    __slots__ = ("t", "parts", "M")
+
+    def __init__(self, t, parts, M):
+        self.t, self.parts, self.M = t, parts, M
 
 
-def _gemm(desc):
+def _gemm(desc, emit_stats=False, device=None):
     lib = _lib.load()
-    desc.tile_cfg = TILE_CFG | TILE_FLAGS
+    desc.tile_cfg = TILE_CFG
+    stream = _stream()
     if SPLITK_WS_BYTES:
-        ws = _splitk_workspace()
+        ws = _splitk_workspace(stream)
         desc.splitk_ws, desc.splitk_ws_bytes = _p(ws), ws.numel() * 4
-    if GEMM_DBG is not None:
-        desc.dbg = _p(GEMM_DBG)
-    check(lib.vk_gemm_bf16(C.byref(desc), _stream()), "vk_gemm_bf16")
+    stats = None
+    if emit_stats:
+        parts = lib.vk_gemm_rowstat_parts(C.byref(desc))
+        if parts <= 0:
+            raise _lib.VistaHipError(f"vk_gemm_rowstat_parts failed with code {parts}")
+        stats = RowStats(torch.empty((parts, desc.M, 2), dtype=F32, device=device), parts, desc.M)
+        desc.rowstat_out = _p(stats.t)
+    check(lib.vk_gemm_bf16(C.byref(desc), stream), "vk_gemm_bf16")
+    return stats
 
 
-def _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta):
+def _fill_ln(d, pw, ln, M):
+    """ln: RowStats of the GEMM's input rows; pw must carry a folded LayerNorm (and vice versa)."""
+    if (ln is None) != (pw.colsum is None):
+        raise ValueError("a weight packed with a folded LayerNorm needs the input's RowStats (ln=...), and only such a weight takes them")
+    if ln is not None:
+        if ln.M != M:
+            raise ValueError(f"RowStats of {ln.M} rows passed to a GEMM over {M} rows")
+        d.ln_stats, d.ln_parts, d.ln_colsum, d.ln_eps = _p(ln.t), ln.parts, _p(pw.colsum), pw.ln_eps
+
+
+def _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta, rowvec2=None):
     d.Wt = _p(pw.wt)
     d.bias = _p(pw.bias)
     d.M, d.N, d.K = M, pw.N, pw.K
@@ -179,31 +223,50 @@ def _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta)
         _need(res2, BF16, "res2")
         r, ld = _rows2d(res2, "res2")
         d.res2, d.ld_res2 = _p(r), ld
+    if rowvec2 is not None:
+        _need(rowvec2, F32, "rowvec2")
+        if res2 is None:
+            raise ValueError("rowvec2 is added to res2 (out = alpha*(...) + beta*(res2 + rowvec2))")
+        if rowvec is not None and rowvec.stride(0) != rowvec2.stride(0):
+            raise ValueError("rowvec and rowvec2 share one row stride")
+        d.rowvec2, d.ldv, d.rows_per_vec = _p(rowvec2), rowvec2.stride(0), int(rows_per_vec)
 
 
-def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0):
-    """out = alpha*(x @ W^T + bias + rowvec[row // rows_per_vec] + res1) + beta*res2.  x: (..., K) bf16."""
+def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0, rowvec2=None,
+           x2=None, ln=None, emit_stats=False):
+    """out = alpha*(X @ W^T + bias + rowvec[row // rows_per_vec] + res1) + beta*(res2 + rowvec2[row // rows_per_vec]).
+    x: (..., K) bf16. x2: second source of a channel concat, X = [x | x2] (never materialised). ln: RowStats of x's rows when pw has
+    a LayerNorm folded in (X = LayerNorm(x)). emit_stats: also return the RowStats of the (bf16) output -> (out, stats)."""
     _need(x, BF16, "x")
-    x2, lda = _rows2d(x, "x")
-    M = x2.shape[0]
-    if x2.shape[1] != pw.K:
-        raise ValueError(f"linear: K mismatch {x2.shape[1]} vs {pw.K}")
+    x2d, lda = _rows2d(x, "x")
+    M = x2d.shape[0]
+    k_in = x2d.shape[1]
+    d = VkGemmDesc()
+    if x2 is not None:
+        _need(x2, BF16, "x2")
+        b2d, ldb = _rows2d(x2, "x2")
+        if b2d.shape[0] != M:
+            raise ValueError("linear: x and x2 must have the same rows")
+        d.A2, d.lda2, d.k_split = _p(b2d), ldb, k_in
+        k_in += b2d.shape[1]
+    if k_in != pw.K:
+        raise ValueError(f"linear: K mismatch {k_in} vs {pw.K}")
     if pw.geglu:
         nout = pw.N // 2
         if out is None:
             out = torch.empty((M, nout), dtype=BF16, device=x.device)
     elif out is None:
         out = torch.empty((M, pw.N), dtype=F32 if out_f32 else BF16, device=x.device)
-    d = VkGemmDesc()
-    d.A, d.lda = _p(x2), lda
+    d.A, d.lda = _p(x2d), lda
     d.amode = AMODE_DENSE
     d.epi = EPI_GEGLU if pw.geglu else EPI_LINEAR
-    _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta)
-    _gemm(d)
-    return out
+    _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta, rowvec2)
+    _fill_ln(d, pw, ln, M)
+    stats = _gemm(d, emit_stats, x.device)
+    return (out, stats) if emit_stats else out
 
 
-def linear_vt(x, pw, S, out=None):
+def linear_vt(x, pw, S, out=None, ln=None):
     """V^T projection for spatial attention: x (n_img*S, K) -> out (n_img, N, S) bf16 = (x @ W^T + bias)^T per image (EPI_TRANS)."""
     _need(x, BF16, "x")
     x2, lda = _rows2d(x, "x")
@@ -218,8 +281,19 @@ def linear_vt(x, pw, S, out=None):
     d.bias = _p(pw.bias)
     d.Wt, d.M, d.N, d.K, d.out, d.ldc, d.S = _p(pw.wt), M, pw.N, pw.K, _p(out), S, S
     d.alpha = 1.0
+    _fill_ln(d, pw, ln, M)
     _gemm(d)
     return out
+
+
+def rowstats(x):
+    """RowStats (one slab) of x (..., C) bf16 by a read-only pass: for tensors whose producer is not a GEMM epilogue on this rank."""
+    _need(x, BF16, "x")
+    x2, ldx = _rows2d(x, "x")
+    M, Cc = x2.shape
+    st = torch.empty((1, M, 2), dtype=F32, device=x.device)
+    check(_lib.load().vk_rowstats_bf16(_p(x2), _p(st), M, Cc, ldx, _stream()), "vk_rowstats_bf16")
+    return RowStats(st, 1, M)
 
 
 def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, rowvec=None, res1=None, res2=None, alpha=1.0,
@@ -364,7 +438,8 @@ def quantize_rows_fp8(x):
     return q, scale
 
 
-def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0):
+def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0,
+               rowvec2=None):
     """out = alpha*((xq*a_scale) @ (Wq*w_scale)^T + bias + rowvec + res1) + beta*res2, fp8 x fp8 -> f32 accumulate."""
     if xq.dtype != torch.uint8 or xq.dim() != 2 or xq.stride(1) != 1:
         raise TypeError("linear_fp8: xq must be a (M, K) uint8 tensor of e4m3 bytes")
@@ -378,7 +453,7 @@ def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_pe
     d.A, d.lda = _p(xq), xq.stride(0)
     d.amode = AMODE_DENSE
     d.epi = EPI_GEGLU if pw.geglu else EPI_LINEAR
-    _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta)
+    _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta, rowvec2)
     d.K = pw.Kp
     d.tile_cfg = TILE_CFG & 7
     check(_lib.load().vk_gemm_fp8(C.byref(d), _p(a_scale), _p(pw.scale), K, _stream()), "vk_gemm_fp8")
@@ -442,6 +517,21 @@ def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None):
     lib = _lib.load()
     check(lib.vk_groupnorm_silu_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), n_img, S, Cc, frames_per_group, float(eps),
                                      1 if silu else 0, _stream()), "vk_groupnorm_silu_bf16")
+    return out
+
+
+def groupnorm_cat(a, b, gamma, beta, eps, silu, frames_per_group=1):
+    """GroupNorm(32)[+SiLU] of the channel concat [a | b] ((n_img, S, C1) and (n_img, S, C2) bf16) -> (n_img, S, C1+C2), without
+    materialising the concat (the skip `torch.cat` of the UNet's output blocks, video_model.py:493)."""
+    _need(a, BF16, "a"); _need(b, BF16, "b")
+    if not (a.is_contiguous() and b.is_contiguous()) or a.shape[:2] != b.shape[:2]:
+        raise ValueError("groupnorm_cat: contiguous (n_img, S, C) inputs with equal n_img, S required")
+    n_img, S, c1 = a.shape
+    c2 = b.shape[2]
+    out = torch.empty((n_img, S, c1 + c2), dtype=BF16, device=a.device)
+    ws = torch.empty(((n_img // frames_per_group) + n_img * ((S + 31) // 32)) * 64, dtype=F32, device=a.device)
+    check(_lib.load().vk_groupnorm_silu_cat_bf16(_p(a), _p(b), _p(out), _p(gamma), _p(beta), _p(ws), n_img, S, c1, c2, frames_per_group,
+                                                 float(eps), 1 if silu else 0, _stream()), "vk_groupnorm_silu_cat_bf16")
     return out
 
 
