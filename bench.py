@@ -1,6 +1,10 @@
 """Headline benchmark: denoise steps/s of the EulerEDM x VideoUNet hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process. N > 1 with no WORLD_SIZE in the environment re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>` (one rank per GPU,
+backend "nccl" = RCCL); when the driver has already launched the ranks (WORLD_SIZE set) each rank just runs.
 
 One "step" = one EulerEDMSampler.sampler_step (reference sampling.py:78-89): mask replace -> CFG-doubled UNet forward on
 50 images (2 x 25 frames, latent 4x72x128 = 576x1024 pixels) -> guider combine -> Euler update, on the 50-step
@@ -10,6 +14,8 @@ sigma schedule. Inputs are synthetic and resident in HBM before the timed region
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,9 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_STEP_CFG = 1.604e14   # algorithmic FLOP of one CFG step at N=50, 72x128 (torch flop counter on the reference)
-ATTN_L0_FLOP = 4.0 * 250 * 9216 * 9216 * 64  # spatial self-attention, level 0: (B*h, N, N, d) = (250, 9216, 9216, 64)
+FLOP_ATTN_PER_STEP = 3.10e13   # of which spatial self-attention cores
 MFMA_BF16_PEAK = 2.5e15        # dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12              # HBM3E spec peak, same guide
 METRIC = "denoise steps/sec, 25-frame 576x1024 latent, 50-step EDM @ 1/2/4/8 GPU"
+EDM = {"target": "vwm.modules.diffusionmodules.discretizer.EDMDiscretization", "params": {"sigma_min": 0.002, "sigma_max": 700.0, "rho": 7.0}}
 
 
 def build_model(model_channels, seed=0):
@@ -45,29 +53,135 @@ def build_model(model_channels, seed=0):
 
 
 def cpu_baseline(net, T, sample_hw, seed):
-    """Times the CPU oracle (fp32 restatement of the reference, oracle/vista_oracle.py) on the host cores for one CFG
-    UNet forward at a reduced latent, counts its FLOPs with torch's flop counter and extrapolates to the full-size step
-    by FLOP ratio. Also returns the GPU-vs-oracle parity at that sample."""
+    """CPU leg, on the host cores, bounded to ~30 s: (a) ONE CFG UNet forward (N = 2T images, full-width weights) at a reduced latent
+    through the fp32 oracle restatement of the reference (oracle/vista_oracle.py) -- or through the reference's own VideoUNet
+    (oracle/ref_shim.py) where /root/reference is mounted -- with its FLOPs counted by torch's flop counter; (b) the spatial
+    self-attention core at the FULL 9216-token level for one image (5 heads), because attention cost is quadratic in the tokens and a
+    FLOP-ratio extrapolation from a 512-token sample alone would understate it. The full-size step is then estimated as
+    attention FLOPs / rate(b) + remaining FLOPs / rate(a). Also returns the GPU-vs-oracle parity at the sample."""
     from torch.utils.flop_counter import FlopCounterMode
-    from oracle import vista_oracle as O
+    from oracle import ref_shim, vista_oracle as O
     from oracle.make_golden import unet_inputs
     h, w = sample_hw
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
     x8, ts, ctx, y, mask = unet_inputs(T, h, w, seed=seed, sigma=7.0)
     cores = torch.get_num_threads()
+    kind = "port"
+    fwd = lambda: O.unet_forward(sd, x8, ts, ctx, y, mask, T)  # noqa: E731
+    if ref_shim.available():  # build container only: time the reference's own modules
+        ref_net = ref_shim.build_ref_unet(**ref_shim.unet_kwargs(net.model_channels))
+        ref_net.load_state_dict(sd, strict=True)
+        kind = "reference"
+        fwd = lambda: ref_net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=T)  # noqa: E731
     with torch.no_grad():
         with FlopCounterMode(display=False) as fc:
             t0 = time.perf_counter()
-            ref = O.unet_forward(sd, x8, ts, ctx, y, mask, T)
+            ref = fwd()
             dt = time.perf_counter() - t0
-    flops = float(fc.get_total_flops())
+        flops = float(fc.get_total_flops())
+        # (b) full-size level-0 attention core, one image: softmax(q k^T / 8) v over 9216 tokens x 5 heads
+        S0 = 72 * 128
+        g = torch.Generator().manual_seed(seed)
+        q, k, v = (torch.randn(5, S0, 64, generator=g) for _ in range(3))
+        t0 = time.perf_counter()
+        s = torch.matmul(q, k.transpose(-1, -2)) * 0.125
+        torch.matmul(torch.softmax(s, dim=-1), v)
+        dt_attn = time.perf_counter() - t0
+        del s
+    attn_rate = 4.0 * 5 * S0 * S0 * 64 / dt_attn
     out = net(x8.cuda(), timesteps=ts.cuda(), context=ctx.cuda(), y=y.cuda(), cond_mask=mask.cuda(), num_frames=T).cpu()
     rel = ((out - ref).pow(2).sum().sqrt() / ref.pow(2).sum().sqrt()).item()
-    steps_per_s = (flops / dt) / FLOP_PER_STEP_CFG
-    return {"value": steps_per_s, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 CFG UNet forward (N={2*T} images, full-width 1.65B weights) at latent {h}x{w} on the host: {dt:.1f} s, "
-                      f"{flops/1e12:.2f} TFLOP counted -> {flops/dt/1e12:.3f} TFLOP/s, extrapolated to the 1.604e14-FLOP full-size step",
+    est_s = FLOP_ATTN_PER_STEP / attn_rate + (FLOP_PER_STEP_CFG - FLOP_ATTN_PER_STEP) / (flops / dt)
+    return {"value": 1.0 / est_s, "unit": "steps/s", "cores": cores, "kind": kind,
+            "sample": f"(a) 1 CFG UNet forward (N={2*T} images, full-width 1.65B weights) at latent {h}x{w} on the host: {dt:.1f} s, "
+                      f"{flops/1e12:.2f} TFLOP counted -> {flops/dt/1e12:.3f} TFLOP/s; (b) level-0 spatial attention core at the full 9216 tokens, "
+                      f"1 image x 5 heads: {dt_attn:.2f} s -> {attn_rate/1e12:.3f} TFLOP/s; full-size step estimated as 3.10e13 attention FLOP at (b) + "
+                      f"1.294e14 other FLOP at (a) = {est_s:.0f} s/step",
             "parity_rel_l2_at_sample": rel}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: become the launcher of N ranks (one per GPU) and relay their exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def plumbing_only(args, world, rank, dist, backend):
+    """Launch / rendezvous / partition check without touching a GPU (CPU test of the N > 1 launch path): builds both shard layouts,
+    round-trips a tensor through the frame<->pixel all-to-alls, the halo exchange and the statistics all-reduce on the host."""
+    from vista_amd.parallel import DistComm, make_shard
+    T = args.frames
+
+    def make_group(ranks):
+        g = dist.new_group(ranks=ranks)
+        return DistComm(g) if rank in ranks else None
+    layouts = {}
+    for mode in ("hybrid", "frames"):
+        sh = make_shard(T, world, rank, mode=mode, make_group=make_group)
+        layouts[mode] = {"t_counts": sh.t_counts, "cfg_half": sh.cfg_half}
+        if sh.P > 1:
+            x = torch.arange(sh.B * sh.t_local * 12 * 4, dtype=torch.float32).view(sh.B * sh.t_local, 12, 4) + 1000 * rank
+            back = sh.to_frames(sh.to_pixels(x), 12)
+            assert torch.equal(back, x), "frame->pixel->frame all-to-all round trip"
+            sh.halo_exchange(x)
+        s = torch.ones(4)
+        sh.all_reduce_sum(s)
+        assert float(s[0]) == sh.P
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert int(t.item()) == world - 1
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "steps/s", "n_gpus": world, "plumbing_only": True, "backend": backend,
+                          "layouts": layouts}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gemm_rooflines(ops, n_img, H, W):
+    """Per-kernel roofline entries for the three GEMM buckets of the kernel trace (level-0 shapes of the BASELINE config), timed here
+    with HIP events on the launch stream, 10 launches each after 2 warm-ups."""
+    dev = "cuda"
+    M, C = n_img * H * W, 320
+    g = torch.Generator(device=dev).manual_seed(1)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+    x = rn(M, C).to(torch.bfloat16)
+    res = rn(M, C).to(torch.bfloat16)
+    pw_lin = ops.pack_linear(rn(C, C) * C ** -0.5, rn(C))
+    pw_geglu = ops.pack_geglu(rn(8 * C, C) * C ** -0.5, rn(8 * C))
+    pw_conv = ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C))
+    x3 = x.view(n_img, H * W, C)
+    cases = [
+        ("gemm_kernel[dense,linear,256x320] level-0 projection 460800x320x320 (+residual)", lambda: ops.linear(x, pw_lin, res1=res),
+         2.0 * M * C * C, 3.0 * M * C * 2, "hbm"),
+        ("gemm_kernel[dense,geglu,256x256] level-0 GEGLU 460800x320->2560 (gated to 1280)", lambda: ops.linear(x, pw_geglu),
+         2.0 * M * 8 * C * C, M * C * 2 + M * 4 * C * 2, "mfma"),
+        ("gemm_kernel[conv3x3,linear,256x320] level-0 conv 320->320 @72x128", lambda: ops.conv3x3(x3, pw_conv, n_img, H, W),
+         2.0 * M * C * 9 * C, 2.0 * M * C * 2, "mfma"),
+    ]
+    out = []
+    for name, fn, flop, byts, bound in cases:
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        tf, gbs = flop / ms / 1e9, byts / ms / 1e6
+        out.append({"kernel": name, "bound": bound, "avg_ms": ms, "tflops": tf, "algorithmic_GBps": gbs,
+                    "achieved": gbs if bound == "hbm" else tf, "peak": HBM_PEAK / 1e9 if bound == "hbm" else MFMA_BF16_PEAK / 1e12,
+                    "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+                    "frac": gbs / (HBM_PEAK / 1e9) if bound == "hbm" else tf / (MFMA_BF16_PEAK / 1e12)})
+    return out
 
 
 def main():
@@ -80,31 +194,41 @@ def main():
     ap.add_argument("--latent-w", type=int, default=128)
     ap.add_argument("--model-channels", type=int, default=320)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side figures (IdentityGuider N=25, GEMM rooflines, config-3 layout)")
     ap.add_argument("--shard", choices=["hybrid", "frames"], default="hybrid")
     ap.add_argument("--cpu-sample", type=str, default="16x32")
+    ap.add_argument("--plumbing-only", action="store_true", help="N > 1: rendezvous + partition/exchange check on the host, no GPU work")
     ap.add_argument("--fp8-ff", action="store_true",
                     help="BASELINE config 5 experiment, NOT the headline: FeedForward GEMMs in fp8 e4m3 (reported dtype says so)")
     args = ap.parse_args()
-    if args.fp8_ff:
-        from vista_amd.modules import attention as _att
-        _att.FP8["feedforward"] = True
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("VISTA_DIST_BACKEND", "nccl")  # "gloo" + VISTA_FORCE_DEVICE=0: dry run of the N>1 path on one GPU
     if "VISTA_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["VISTA_FORCE_DEVICE"])
-    torch.cuda.set_device(local_rank)
     dist = None
-    shard = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.plumbing_only:
+            dist.init_process_group("gloo")
+            return plumbing_only(args, world, rank, dist, "gloo")
+        torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
+    else:
+        torch.cuda.set_device(local_rank)
+    if args.fp8_ff:
+        from vista_amd.modules import attention as _att
+        _att.FP8["feedforward"] = True
     from vista_amd import _lib, ops, synth
     from vista_amd.modules.diffusionmodules.denoiser import Denoiser
     from vista_amd.modules.diffusionmodules.sampling import EulerEDMSampler, FusedDenoiser, FusedLoop
@@ -112,6 +236,7 @@ def main():
     _lib.load()
 
     T, H, W = args.frames, args.latent_h, args.latent_w
+    shards = {None: None}
     if world > 1:
         from vista_amd.parallel import DistComm, make_shard
 
@@ -119,43 +244,54 @@ def main():
             g = dist.new_group(ranks=ranks)
             return DistComm(g) if rank in ranks else None
         # 'hybrid' (default): CFG halves x frame groups -- 8 GPUs = 2 x (7/6/6/6); 'frames': 4/3/3/3/3/3/3/3 (BASELINE config 3)
-        shard = make_shard(T, world, rank, mode=args.shard, make_group=make_group)
+        shards = {args.shard: make_shard(T, world, rank, mode=args.shard, make_group=make_group)}
+        other = "frames" if args.shard == "hybrid" else "hybrid"
+        if not args.no_extras and world % 2 == 0:  # odd worlds have one layout only
+            shards[other] = make_shard(T, world, rank, mode=other, make_group=make_group)
     net = build_model(args.model_channels)
     w = synth.window_inputs(T=T, H=H, W=W, seed=0)
     cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
     den = Denoiser(scaling_config={"target": "vwm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
-    sampler = EulerEDMSampler(num_steps=50, discretization_config={"target": "vwm.modules.diffusionmodules.discretizer.EDMDiscretization",
-                                                                   "params": {"sigma_min": 0.002, "sigma_max": 700.0, "rho": 7.0}},
+    sampler = EulerEDMSampler(num_steps=50, discretization_config=EDM,
                               guider_config={"target": "vwm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 2.5}}, device="cuda")
     noise = w["noise"].cuda()
     x, sigmas, _, cond, uc = sampler.prepare_sampling_loop(noise, cu(w["c"]), cu(w["uc"]))
     sig = [float(s) for s in sigmas]
-    loop = FusedLoop(sampler, FusedDenoiser(den, OpenAIWrapper(net)), x.float().clone(), cond, uc, w["cond_frame"].cuda(),
-                     w["cond_mask"].cuda(), True, sig, shard=shard)
     nsteps = len(sig) - 1
     assert args.warmup + args.steps <= nsteps, "at most 50 steps per window"
-    for i in range(args.warmup):
-        loop.step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    ops.PROFILE_ATTN = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        loop.step(i)
-    t_enqueue = time.perf_counter() - t0  # host time to enqueue the steps (before any sync)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    fd = FusedDenoiser(den, OpenAIWrapper(net))
+
+    def timed_loop(shard, profile_attn):
+        """W warm-up + K timed steps of a fresh window; returns (seconds for K steps = MAX over ranks, host enqueue seconds, loop)."""
+        loop = FusedLoop(sampler, fd, x.float().clone(), cond, uc, w["cond_frame"].cuda(), w["cond_mask"].cuda(), True, sig, shard=shard)
+        for i in range(args.warmup):
+            loop.step(i)
         torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:  # MAX over ranks
-        tdt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-        dt = float(tdt.item())
+        if dist is not None:
+            dist.barrier()
+        if profile_attn:
+            ops.PROFILE_ATTN = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, args.warmup + args.steps):
+            loop.step(i)
+        t_enq = time.perf_counter() - t0  # host time to enqueue the steps (before any sync)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:  # MAX over ranks
+            tdt = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+            dt = float(tdt.item())
+        assert torch.isfinite(loop.xw).all(), "non-finite latents"
+        return dt, t_enq, loop
+
+    main_key = args.shard if world > 1 else None
+    shard = shards[main_key]
+    dt, t_enqueue, _ = timed_loop(shard, True)
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
-    assert torch.isfinite(loop.xw).all(), "non-finite latents"
     ms_per_step = dt * 1e3 / args.steps
     value = args.steps / dt
     full = (T, H, W, args.model_channels) == (25, 72, 128, 320)
@@ -174,17 +310,22 @@ def main():
             traffic = json.load(open(tp))["traffic_bytes_per_launch"]
         roofline = {"kernel": "attn_spatial_kernel (level-0 spatial self-attention)", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": traffic,
+                    "traffic_source": "rocprofv3 PMC passes of the same kernel and shape, profiles/r01_attn_traffic.json (not re-measured in this run)",
                     "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop}
+
+    def layout(sh):
+        return (("CFG-split x2 x " if sh.cfg_half is not None else "") + "frame-sharded " + "/".join(str(c) for c in sh.t_counts)) if sh else "single GPU"
     res = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16 + fp8(e4m3) FeedForward GEMMs [config 5 experiment]" if args.fp8_ff else "bf16",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16 + fp8(e4m3) FeedForward GEMMs [config 5 experiment]" if args.fp8_ff else "bf16",
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (DRY RUN: gloo host-staged transport, ranks share one GPU -- not a result)",
-        "config": {"workload": (f"{world}xMI355X" + ((" CFG-split x2 x" if shard.cfg_half is not None else "") + " frame-sharded " +
-                                                     "/".join(str(c) for c in shard.t_counts) if shard else "") +
+        "config": {"workload": (f"{world}xMI355X " + layout(shard) +
                                 ": 25x576x1024 (latent 25x4x72x128), 50-step EulerEDM, VanillaCFG 2.5 (N=50 images per UNet call), "
                                 "bf16, random-init 1.65B VideoUNet, synthetic latents") if full else
-                   f"REDUCED (not the BASELINE config): T={T} latent {H}x{W} model_channels={args.model_channels}",
+                   f"REDUCED (not the BASELINE config): T={T} latent {H}x{W} model_channels={args.model_channels}, {world} rank(s) " + layout(shard),
                    "frames": T, "latent": [4, H, W], "cfg_images_per_call": 2 * T, "sampler": "EulerEDM s_churn=0, 50-step schedule",
+                   "t_counts": shard.t_counts if shard else [T], "shard": main_key,
                    "windows_per_s": value / 50.0,
                    "parallelism": "single GPU" if shard is None else
                    (("CFG halves on 2 rank groups (one output exchange per step) x " if shard.cfg_half is not None else "") +
@@ -194,6 +335,36 @@ def main():
         "host_enqueue_ms_per_step": t_enqueue * 1e3 / args.steps,
         "step_mfma_frac": (FLOP_PER_STEP_CFG / (ms_per_step * 1e-3) / (MFMA_BF16_PEAK * world)) if full else None,
     }
+    # ---- side figures (never `value`) ----
+    if not args.no_extras:
+        for key, sh in shards.items():  # the other multi-GPU layout, e.g. BASELINE config 3's 4/3/3/3/3/3/3/3 next to the hybrid default
+            if key == main_key:
+                continue
+            dt2, _, _ = timed_loop(sh, False)
+            res["config3_frames_layout" if key == "frames" else "hybrid_layout"] = {
+                "layout": layout(sh), "t_counts": sh.t_counts, "value": args.steps / dt2, "ms_per_step": dt2 * 1e3 / args.steps}
+        if world == 1:
+            # N = 25 images per UNet call (IdentityGuider: no classifier-free guidance), through the reference-shaped generic sampler path
+            ident = EulerEDMSampler(num_steps=50, discretization_config=EDM, guider_config=None, device="cuda")
+            xi = x.float().clone()
+            n = xi.shape[0]
+            maskf = w["cond_mask"].cuda().float()
+
+            def ident_step(i):
+                s0, s1 = torch.full((n,), sig[i], device="cuda"), torch.full((n,), sig[i + 1], device="cuda")
+                return ident.sampler_step(s0, s1, fd, xi, cond, maskf, uc, 0.0)
+            for i in range(args.warmup):
+                ident_step(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.warmup, args.warmup + args.steps):
+                ident_step(i)
+            torch.cuda.synchronize()
+            dti = time.perf_counter() - t0
+            res["identity_guider_n25"] = {"value": args.steps / dti, "unit": "steps/s", "ms_per_step": dti * 1e3 / args.steps,
+                                          "note": "IdentityGuider: one UNet forward on N=25 images per step (half the CFG work), generic sampler path"}
+            if full:
+                res["roofline_gemm"] = gemm_rooflines(ops, 2 * T, H, W)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         h, wd = (int(v) for v in args.cpu_sample.split("x"))
         res["cpu_baseline"] = cpu_baseline(net, T, (h, wd), seed=1)

@@ -110,8 +110,14 @@ def cross_attention(sd, p, x, context=None, action_control=False, context_dim=10
         v = v + F.linear(ctx_act, sd[p + ".v_adapter_action_control.weight"])
     b = q.shape[0]
     q, k, v = _heads(q, heads), _heads(k, heads), _heads(v, heads)
-    s = torch.matmul(q, k.transpose(-1, -2)) * (q.shape[-1] ** -0.5)
-    out = torch.matmul(torch.softmax(s, dim=-1), v)
+    # same arithmetic per (image, head); the batch is walked in slices so the score matrix of the 9216-token level
+    # (250 heads x 9216 x 9216 fp32 = 85 GB at once) stays below ~2 GB
+    step = max(1, int(2 ** 29 // max(1, q.shape[1] * k.shape[1])))
+    outs = []
+    for i in range(0, q.shape[0], step):
+        s = torch.matmul(q[i:i + step], k[i:i + step].transpose(-1, -2)) * (q.shape[-1] ** -0.5)
+        outs.append(torch.matmul(torch.softmax(s, dim=-1), v[i:i + step]))
+    out = outs[0] if len(outs) == 1 else torch.cat(outs, 0)
     out = out.view(b, heads, out.shape[1], -1).permute(0, 2, 1, 3).reshape(b, out.shape[1], -1)
     return _lin(sd, p + ".to_out.0", out)
 

@@ -184,3 +184,59 @@ def test_eight_ranks_25_frames_hybrid_and_frames_layouts_vs_config1_golden():
         r = rel_l2(outs[0], g["out"].float())
         print(f"[parity] 8 ranks, 25 frames, 10 steps, {mode}: rel-L2 {r:.3e}")
         assert r <= 4e-2
+
+
+# ------------------------------------------------------------------------------------------------ real process groups
+def _run(cmd, env_extra, timeout=900):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-6000:]
+    import json
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert lines, r.stdout[-3000:]
+    return json.loads(lines[-1])
+
+
+def _torchrun(n, port, script, *args):
+    import sys
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port",
+            str(port), script, *args]
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_gpus_2_end_to_end_dry_run_on_one_gpu():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: bench.py spawns the two ranks itself and the whole multi-rank path (both shard
+    layouts, exchanges, MAX-over-ranks timing, one JSON line) runs -- here host-staged over gloo with both ranks on GPU 0 (labelled a dry
+    run in `data`); on a multi-GPU node the same command runs over RCCL."""
+    import sys
+    res = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames", "5", "--latent-h", "16",
+                "--latent-w", "32", "--model-channels", "64", "--no-cpu-baseline"], {"VISTA_DIST_BACKEND": "gloo", "VISTA_FORCE_DEVICE": "0"})
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["steps"] == 2
+    assert res["config"]["t_counts"] == [5] and res["config"]["shard"] == "hybrid"
+    assert res["config3_frames_layout"]["t_counts"] == [3, 2] and res["config3_frames_layout"]["value"] > 0
+    assert "DRY RUN" in res["data"]
+
+
+@pytest.mark.parametrize("mode", ["hybrid", "frames"])
+def test_two_process_gloo_ranks_on_one_gpu_match_golden(mode):
+    """Real torch.distributed process group (2 OS processes, gloo, host-staged transport, both on GPU 0) through DistComm."""
+    res = _run(_torchrun(2, 29641 if mode == "hybrid" else 29642, os.path.join(ROOT, "tests", "_dist_worker.py"), mode),
+               {"VISTA_DIST_BACKEND": "gloo", "VISTA_FORCE_DEVICE": "0"})
+    assert res["world"] == 2 and all(r <= 4e-2 for r in res["rel_l2"]) and all(res["cond_frame_exact"])
+    assert len(set(res["checksums"])) == 1, "every rank must end with the same window"
+    print(f"[parity] 2 gloo processes, {mode}: rel-L2 {res['rel_l2']}")
+
+
+@pytest.mark.parametrize("mode", ["hybrid", "frames"])
+def test_two_ranks_over_rccl_match_golden(mode):
+    """One process per GPU over RCCL (backend "nccl"); needs two visible GPUs (skipped on the 1-GPU test boxes)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    res = _run(_torchrun(2, 29643 if mode == "hybrid" else 29644, os.path.join(ROOT, "tests", "_dist_worker.py"), mode), {"VISTA_DIST_BACKEND": "nccl"})
+    assert res["world"] == 2 and res["backend"] == "nccl" and all(r <= 4e-2 for r in res["rel_l2"]) and all(res["cond_frame_exact"])
+    assert len(set(res["checksums"])) == 1

@@ -33,7 +33,9 @@ def default(val, d):
 class Packable:
     """Lazy bf16 weight packing (ops.pack_*). The pack is keyed on the device, dtype and in-place version counters of the
     parameters it was built from, so it is rebuilt after `.cuda()`, after ANY load_state_dict (also one issued on a parent
-    container, which never reaches the children's own load_state_dict) and after in-place updates (EMA swap, `p.data.copy_`)."""
+    container, which never reaches the children's own load_state_dict) and after in-place updates of the Parameters
+    (`p.copy_()`, `p.mul_()` under no_grad). Writes through `p.data` (the reference's LitEma.copy_to, vwm/modules/ema.py) carry
+    their own version counter by PyTorch's design and are invisible here: call `invalidate_packed(model)` after them."""
     _pk = None
     _pk_key = None
     _pk_params = None
@@ -62,6 +64,13 @@ class Packable:
     def invalidate_packed(self):
         self._pk = None
         object.__setattr__(self, "_pk_params", None)  # a replaced nn.Parameter object is picked up on the next pack
+
+
+def invalidate_packed(module):
+    """Drop every packed weight under `module` (needed only after writes through `param.data`, e.g. an EMA swap)."""
+    for m in module.modules():
+        if isinstance(m, Packable):
+            m.invalidate_packed()
 
 
 class GEGLU(nn.Module):

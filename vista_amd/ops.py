@@ -4,8 +4,9 @@ PyTorch is used for device memory (caching allocator), streams and views only; e
 hand-written gfx950 kernel in libvista_hip.so. Activations are token-major bf16: (n_img, S=H*W, C), C contiguous.
 """
 import ctypes as C
-import os
 import math
+import os
+import threading
 
 import torch
 
@@ -157,9 +158,9 @@ _SPLITK_WS = {}
 
 
 def _splitk_workspace(stream):
-    """One workspace per (device, stream): launches on one stream are ordered, so they may share it; GEMMs in flight on
+    """One workspace per (device, stream, host thread): launches on one stream are ordered, so they may share it; GEMMs in flight on
     different streams must not (include/vista_hip.h, VkGemmDesc.splitk_ws)."""
-    key = (torch._C._cuda_getDevice(), stream.value)
+    key = (torch._C._cuda_getDevice(), stream.value, threading.get_ident())  # thread ranks (tests) share a stream but enqueue concurrently
     ws = _SPLITK_WS.get(key)
     if ws is None:
         ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{key[0]}")
