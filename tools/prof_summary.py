@@ -46,6 +46,16 @@ def main():
         print("\nattn_spatial_kernel by launch geometry (grid_x = threads):")
         for n, gx, wx, c, avg, tot in rows:
             print(f"  {short(n):28s} grid_x {gx:9d} wg {wx:4d}  calls {c:4d}  avg_us {avg/1e3:9.2f}  total_ms {tot/1e6:8.2f}")
+    # the GEMM family by launch geometry (one line per distinct problem shape class): where the step's GEMM time goes
+    try:
+        rows = list(db.execute("select name, grid_x, workgroup_x, count(*), avg(duration), sum(duration) from kernels "
+                               "where name like '%gemm_kernel%' group by name, grid_x, workgroup_x order by sum(duration) desc limit 28"))
+    except sqlite3.Error:
+        rows = []
+    if rows:
+        print("\ngemm_kernel by launch geometry (grid_x = threads = workgroups x workgroup size), top 28 by total time:")
+        for n, gx, wx, c, avg, tot in rows:
+            print(f"  {short(n):44s} wgs {gx // wx:6d} x {wx:4d}  calls {c:4d}  avg_us {avg/1e3:9.2f}  total_ms {tot/1e6:8.2f}")
 
 
 if __name__ == "__main__":

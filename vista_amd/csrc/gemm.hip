@@ -45,7 +45,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     constexpr int FX = TR ? FM : FN, FY = TR ? FN : FM;  // MFMA row-operand / column-operand fragments per wave
     static_assert(BM % RPP == 0 && BN % 8 == 0, "A rows must be a multiple of the staging pass, W rows of a wave's 8-row slice");
     constexpr bool FRAG_DB = (NT <= 512) || (FX * FY <= 4);  // 16 waves x 32x160 wave tiles: no registers for double-buffered fragments
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    // ONE LDS object (a second __shared__ array makes hipcc drain vmcnt before every K-step's first ds_read): two tile stages, then the
+    // (mean, rstd) table of the tile's BM activation rows for the folded LayerNorm
+    constexpr int LN_OFF = 2 * STAGE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + BM * 8];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -260,6 +263,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         mma(xb, yb);
     };
     const int nk = kt1;
+    if (p.ln_stats != nullptr) {  // row statistics of this tile's activation rows -> LDS (visible after the prologue barrier below)
+        for (int r = tid; r < BM; r += NT) {
+            const int m = m0 + r;
+            ((float2*)(smem + LN_OFF))[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
+        }
+    }
     // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
     // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
     dma_tile(kt0, kt0 & 1);
@@ -283,7 +292,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             return;
         }
     }
-    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn);
+    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn,
+                                                p.ln_stats != nullptr ? (const float2*)(smem + LN_OFF) : nullptr);
 }
 
 // Second pass of a split-K GEMM: out = alpha*(sum_s partial[s] + bias + rowvec + res1) + beta*res2, partials summed in slice order

@@ -25,31 +25,29 @@ __device__ __forceinline__ uint4 widen_pair(uint2 qa, uint2 qb) {
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
 
-// LayerNorm fold (VkGemmDesc.ln_*): statistics of activation row m from the producer's partial sums, summed in slab order.
-struct LnFold {
-    const float2* st;
-    const float* cs;
-    int parts, M;
-    float inv_c, eps;
-    __device__ __forceinline__ explicit LnFold(const VkGemmDesc& p)
-        : st((const float2*)p.ln_stats), cs(p.ln_colsum), parts(p.ln_parts), M(p.M), inv_c(1.f / (float)p.K), eps(p.ln_eps) {}
-    __device__ __forceinline__ void row(int m, float& mu, float& rs) const {
-        float s = 0.f, q = 0.f;
-        for (int i = 0; i < parts; ++i) {
-            const float2 v = st[(size_t)i * M + m];
-            s += v.x;
-            q += v.y;
-        }
-        mu = s * inv_c;
-        rs = rsqrtf(fmaxf(q * inv_c - mu * mu, 0.f) + eps);
+// LayerNorm fold (VkGemmDesc.ln_*): (mean, rstd) of activation row m from the producer's partial sums, summed in slab order. The GEMM
+// kernel evaluates this ONCE per tile row at kernel start (the HBM latency of the slab reads hides behind the first tile's DMA) and
+// parks the pairs in LDS; the epilogues read them back with ds_read -- reading the slabs from the epilogue itself exposed ~2 us of
+// HBM latency per tile with nothing to overlap it (one workgroup per CU): +15-20 % on the level-0 GEGLU / q|k|v kernels.
+__device__ __forceinline__ float2 ln_row_stats(const VkGemmDesc& p, int m) {
+    const float2* __restrict__ st = (const float2*)p.ln_stats;
+    float s = 0.f, q = 0.f;
+    for (int i = 0; i < p.ln_parts; ++i) {
+        const float2 v = st[(size_t)i * p.M + m];
+        s += v.x;
+        q += v.y;
     }
-};
+    const float inv_c = 1.f / (float)p.K;
+    const float mu = s * inv_c;
+    return make_float2(mu, rsqrtf(fmaxf(q * inv_c - mu * mu, 0.f) + p.ln_eps));
+}
 
 template <int EPI, bool OUT_F32, int FX, int FY, int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
-                                              int stat_part = 0) {
+                                              int stat_part = 0, const float2* lnrow = nullptr) {
+    // lnrow: LDS table of (mean, rstd) for the tile's rows m0 .. m0 + BM (NULL = no LayerNorm fold)
     constexpr int MW = FM * 32, NW = FN * 32;
-    const LnFold ln(p);
+    const float* __restrict__ lncs = p.ln_colsum;
     if (EPI == EPI_LINEAR) {
         const float* __restrict__ bias = p.bias;
         const float* __restrict__ rowvec = p.rowvec;
@@ -65,7 +63,7 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
             const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
             const float* rv2 = rowvec2 ? rowvec2 + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
             float mu = 0.f, rs = 1.f;
-            if (ln.st) ln.row(m, mu, rs);
+            if (lnrow) { const float2 t = lnrow[m - m0]; mu = t.x; rs = t.y; }
             float ssum = 0.f, qsum = 0.f;  // row sums of the bf16-rounded outputs this lane stores (rowstat_out)
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
@@ -78,8 +76,8 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
-                    if (ln.st) {
-                        const float4 c = *(const float4*)(ln.cs + n);
+                    if (lnrow) {
+                        const float4 c = *(const float4*)(lncs + n);
                         v[0] = rs * (v[0] - mu * c.x); v[1] = rs * (v[1] - mu * c.y);
                         v[2] = rs * (v[2] - mu * c.z); v[3] = rs * (v[3] - mu * c.w);
                     }
@@ -145,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
             const int m = m0 + wm * MW + fj * 32 + l31;
             if (m >= p.M) continue;
             float mu = 0.f, rs = 1.f;
-            if (ln.st) ln.row(m, mu, rs);
+            if (lnrow) { const float2 t = lnrow[m - m0]; mu = t.x; rs = t.y; }
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 const int nfrag = n0 + wn * NW + fi * 32;  // first packed row of the fragment
@@ -159,9 +157,9 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     float a[4], gt[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] = acc[fi][fj][4 * g + e]; gt[e] = acc[fi][fj][4 * (g + 2) + e]; }
-                    if (ln.st) {
-                        const float4 ca = *(const float4*)(ln.cs + np);
-                        const float4 cg = *(const float4*)(ln.cs + np + 16);
+                    if (lnrow) {
+                        const float4 ca = *(const float4*)(lncs + np);
+                        const float4 cg = *(const float4*)(lncs + np + 16);
                         a[0] = rs * (a[0] - mu * ca.x); a[1] = rs * (a[1] - mu * ca.y); a[2] = rs * (a[2] - mu * ca.z); a[3] = rs * (a[3] - mu * ca.w);
                         gt[0] = rs * (gt[0] - mu * cg.x); gt[1] = rs * (gt[1] - mu * cg.y); gt[2] = rs * (gt[2] - mu * cg.z); gt[3] = rs * (gt[3] - mu * cg.w);
                     }
@@ -189,7 +187,7 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
             const int n = n0 + wn * NW + fj * 32 + l31;
             if (n >= p.N) continue;
             const float bn = p.bias ? p.bias[n] : 0.f;  // the lane's output channel (VAE AttnBlock v projection carries a bias)
-            const float csn = ln.st ? ln.cs[n] : 0.f;
+            const float csn = lnrow ? lncs[n] : 0.f;
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 uint2 packed[4];
@@ -198,15 +196,11 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
-                    if (ln.st) {  // the lane's 4 consecutive keys are 4 activation rows: one (mean, rstd) pair each
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            int mr = m0 + wm * MW + fi * 32 + 8 * g + 4 * lh + e;
-                            if (mr >= p.M) mr = p.M - 1;
-                            float mu, rs;
-                            ln.row(mr, mu, rs);
-                            v[e] = rs * (v[e] - mu * csn);
-                        }
+                    if (lnrow) {  // the lane's 4 consecutive keys are 4 activation rows: one (mean, rstd) pair each, 32 contiguous LDS bytes
+                        const float4* t = (const float4*)(lnrow + wm * MW + fi * 32 + 8 * g + 4 * lh);
+                        const float4 t01 = t[0], t23 = t[1];
+                        v[0] = t01.y * (v[0] - t01.x * csn); v[1] = t01.w * (v[1] - t01.z * csn);
+                        v[2] = t23.y * (v[2] - t23.x * csn); v[3] = t23.w * (v[3] - t23.z * csn);
                     }
                     packed[g].x = pack_bf16(v[0] + bn, v[1] + bn);
                     packed[g].y = pack_bf16(v[2] + bn, v[3] + bn);
