@@ -1,0 +1,69 @@
+"""Round-2 A/B sweep of the GEMM main-loop experiment bits (ops.TILE_FLAGS: 8 = staggered DMA issue, 16 = MFMA priority) on the BASELINE
+shapes, including the folded-LayerNorm consumers and the row-sum emitting producers. Interleaved rounds, best of 3 x 10 launches per
+variant; one JSON line per shape: TFLOP/s by flag value.   usage: python tools/gemm_sweep2.py [flags,flags,...]"""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vista_amd import ops  # noqa: E402
+
+BF16 = torch.bfloat16
+
+
+class Norm:
+    def __init__(self, C):
+        self.weight, self.bias, self.eps = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), 1e-5
+
+
+def timeit(fn, iters=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    flags = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,8,16,24".split(","))]
+    N = 50
+    rn = lambda *s: torch.randn(*s, device="cuda")  # noqa: E731
+    for C, H, W in ((320, 72, 128), (640, 36, 64), (1280, 18, 32)):
+        M = N * H * W
+        x = rn(M, C).to(BF16)
+        res = rn(M, C).to(BF16)
+        h4 = rn(M, 4 * C).to(BF16)
+        st = ops.rowstats(x)
+        nrm = Norm(C)
+        x3 = x.view(N, H * W, C)
+        cases = {
+            "linear+res+stats": (lambda pw=ops.pack_linear(rn(C, C) * C ** -0.5, rn(C)): ops.linear(x, pw, res1=res, emit_stats=True), 2.0 * M * C * C),
+            "qkv_lnfold": (lambda pw=ops.pack_linear_cat([rn(C, C) * C ** -0.5 for _ in range(3)], ln=nrm): ops.linear(x, pw, ln=st), 2.0 * M * 3 * C * C),
+            "geglu_lnfold": (lambda pw=ops.pack_geglu(rn(8 * C, C) * C ** -0.5, rn(8 * C), ln=nrm): ops.linear(x, pw, ln=st), 2.0 * M * 8 * C * C),
+            "geglu_plain": (lambda pw=ops.pack_geglu(rn(8 * C, C) * C ** -0.5, rn(8 * C)): ops.linear(x, pw), 2.0 * M * 8 * C * C),
+            "ff_out+res+stats": (lambda pw=ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C)): ops.linear(h4, pw, res1=res, emit_stats=True),
+                                 2.0 * M * 4 * C * C),
+            "conv3x3": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, N, H, W), 2.0 * M * 9 * C * C),
+            "conv_t3": (lambda pw=ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C)): ops.conv_t3(x3, pw, 25, H * W), 2.0 * M * 3 * C * C),
+        }
+        for name, (fn, flop) in cases.items():
+            best = {}
+            for _ in range(3):
+                for f in flags:
+                    ops.TILE_FLAGS = f
+                    best[f] = min(best.get(f, 1e9), timeit(fn))
+            ops.TILE_FLAGS = 0
+            print(json.dumps({"level_C": C, "kind": name, "M": M, "TFLOPs_by_flags": {str(f): round(flop / ms / 1e9) for f, ms in best.items()},
+                              "ms_by_flags": {str(f): round(ms, 4) for f, ms in best.items()}}), flush=True)
+        del x, res, h4, cases
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     constexpr int AP = BM / RPP, WP = (BN + RPP - 1) / RPP;   // staging passes for the A / W tiles (the last W pass may be partial)
     constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
     constexpr bool TR = (EPI == EPI_TRANS);
+    constexpr bool PERSIST = (EPI == EPI_GEGLU);
     constexpr int FX = TR ? FM : FN, FY = TR ? FN : FM;  // MFMA row-operand / column-operand fragments per wave
     static_assert(BM % RPP == 0 && BN % 8 == 0, "A rows must be a multiple of the staging pass, W rows of a wave's 8-row slice");
     constexpr bool FRAG_DB = (NT <= 512) || (FX * FY <= 4);  // 16 waves x 32x160 wave tiles: no registers for double-buffered fragments
@@ -50,17 +51,26 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     constexpr int LN_OFF = 2 * STAGE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + BM * 8];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, lh = lane >> 5;
-
     const int tilesN = (p.N + BN - 1) / BN;
     const int tilesM = (p.M + BM - 1) / BM;
     // split-K (small-M problems): workgroup = (K slice, tile), K slice as the slow index so neighbours still share weight tiles
     const int ntiles = tilesM * tilesN;
-    const int lin = xcd_remap(blockIdx.x, ntiles * ksplit);
+    // PERSIST (GEGLU kernels): a launch of 256 workgroups walks the tile list with stride gridDim.x instead of one workgroup per tile: no
+    // workgroup drain / dispatch between tiles, and the next tile's first DMA overlaps the previous tile's store drain (+3-6 % on the
+    // GEGLU shapes, whose gelu epilogue is the longest; neutral to -3 % on the other epilogues, which keep one workgroup per tile --
+    // profiles/r02_gemm_sweep_persistent_experiment.jsonl). No state is carried across tiles except the loop counter; gridDim.x is a
+    // multiple of 8, so a workgroup's tiles stay in its XCD's range of the remap.
+    const int total_wg = ntiles * ksplit;
+    int bid = blockIdx.x;
+  do {
+    int tid = threadIdx.x;
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid));  // opaque per iteration: keeps the lane-derived address state from being hoisted
+                                                          // out of the tile loop (hoisted, it stays live across the body and spills)
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int lin = xcd_remap(bid, total_wg);
     const int kslice = lin / ntiles, logical = lin - kslice * ntiles;
     const int tn = logical % tilesN, tm = logical / tilesN;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -263,15 +273,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         mma(xb, yb);
     };
     const int nk = kt1;
-    if (p.ln_stats != nullptr) {  // row statistics of this tile's activation rows -> LDS (visible after the prologue barrier below)
+    // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
+    // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
+    dma_tile(kt0, kt0 & 1);
+    if (p.ln_stats != nullptr) {
+        // row statistics of this tile's activation rows -> LDS. Issued AFTER the first tile's DMA so that both HBM round trips are in
+        // flight together (the other order serialised them: +1.5 us per tile); visible to every wave after the barrier below.
         for (int r = tid; r < BM; r += NT) {
             const int m = m0 + r;
             ((float2*)(smem + LN_OFF))[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
         }
     }
-    // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
-    // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
-    dma_tile(kt0, kt0 & 1);
     __syncthreads();
     for (int kt = kt0; kt < nk; ++kt) {
         const int stage = kt & 1;
@@ -289,11 +301,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             q.alpha = 1.f; q.beta = 0.f;
             q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr;
             gemm_epilogue<EPI_LINEAR, true, FX, FY, FM, FN>(q, acc, m0, n0, wm, wn, l31, lh);
-            return;
+            continue;  // (split-K launches are never persistent: one slice-tile per workgroup)
         }
     }
     gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn,
                                                 p.ln_stats != nullptr ? (const float2*)(smem + LN_OFF) : nullptr);
+    if (PERSIST && bid + (int)gridDim.x < total_wg) __syncthreads();  // the next tile rewrites the LDS row-statistics table and stage 0
+  } while (PERSIST && (bid += gridDim.x) < total_wg);
 }
 
 // Second pass of a split-K GEMM: out = alpha*(sum_s partial[s] + bias + rowvec + res1) + beta*res2, partials summed in slice order
@@ -350,7 +364,12 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream, int ksplit = 1) {
     // Activation rows that at most 4 column-tiles ever read are streamed with the non-temporal policy: they would only evict the
     // weight tile every workgroup shares (measured +6-8 % on the K=320 level-0 projections, -5-11 % when 10+ column tiles re-read A).
     desc.tile_cfg = (desc.tile_cfg & ~32) | ((AMODE == AMODE_DENSE && tilesN <= 4) ? 32 : 0);
-    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN>), dim3(tilesM * tilesN * ksplit), dim3(WM * WN * 64), 0, stream, desc, ksplit);
+    int grid = tilesM * tilesN * ksplit;
+    if (EPI == EPI_GEGLU) {  // persistent tile walk (see the kernel): one (two for the 8-wave 128x128 variant) resident workgroup per CU
+        const int resident = 256 * ((WM * WN == 16) ? 1 : 2);
+        if (grid > resident) grid = resident;
+    }
+    hipLaunchKernelGGL((gemm_kernel<AMODE, EPI, OUT_F32, WM, WN, FM, FN>), dim3(grid), dim3(WM * WN * 64), 0, stream, desc, ksplit);
     VK_CHECK_LAUNCH();
     if (ksplit > 1) {
         const long long quads = (long long)d->M * (d->N >> 2);
