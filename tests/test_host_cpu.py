@@ -177,3 +177,57 @@ def test_weight_packing_layouts_on_cpu():
     assert ((deq - w8).abs() <= w8.abs() * 2 ** -4 + p8.scale[:40, None] * 2 ** -9 + 1e-12).all()
     with pytest.raises(ValueError):
         ops.geglu_perm(24)
+
+
+def test_layernorm_fold_packing_algebra_on_cpu():
+    """pack_*(..., ln=norm) must satisfy  LN(x) W^T + b == rstd * (x W'^T - mean * colsum) + bias'  (include/vista_hip.h, VkGemmDesc.ln_*),
+    with colsum taken from the bf16-ROUNDED W' so that the mean term cancels exactly in the kernel's epilogue. Pure host check (no launch):
+    the GEMM is emulated in fp32 from the packed operands; the GPU tests check the kernels against the same identity."""
+    import torch.nn.functional as F
+    from vista_amd import ops
+
+    class Norm:
+        pass
+    g = torch.Generator().manual_seed(0)
+    C, N, M = 128, 96, 40
+    norm = Norm()
+    norm.weight, norm.bias, norm.eps = 1.0 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g), 1e-5
+    w, b = torch.randn(N, C, generator=g) * C ** -0.5, torch.randn(N, generator=g)
+    x = (torch.randn(M, C, generator=g) * 2.0 + 5.0 * torch.randn(M, 1, generator=g)).to(torch.bfloat16).float()  # large row means
+
+    def emulate(pw, rows):
+        acc = rows @ pw.wt[:pw.N].float().t()
+        mean = rows.mean(1, keepdim=True)
+        rstd = (rows.var(1, unbiased=False, keepdim=True) + pw.ln_eps).rsqrt()
+        return rstd * (acc - mean * pw.colsum[:pw.N]) + pw.bias[:pw.N]
+    pw = ops.pack_linear(w, b, device="cpu", ln=norm)
+    assert pw.colsum is not None and torch.equal(pw.colsum, pw.wt.float().sum(1)) and pw.ln_eps == 1e-5
+    ref = F.layer_norm(x, (C,), norm.weight, norm.bias, norm.eps) @ w.t() + b
+    got = emulate(pw, x)
+    assert (got - ref).abs().max() <= 2e-2 * ref.abs().max(), "only the bf16 rounding of gamma (.) W separates the two forms"
+    # exactness of the cancellation: a constant added to a row changes nothing (LayerNorm is shift invariant), to fp32 round-off
+    shifted = emulate(pw, x + 64.0)
+    assert (shifted - got).abs().max() <= 2e-3 * ref.abs().max()
+    # GEGLU: same identity in the packed (value | gate) row order; cat: q|k|v share the fold
+    wg, bg = torch.randn(2 * 64, C, generator=g) * C ** -0.5, torch.randn(2 * 64, generator=g)
+    pg = ops.pack_geglu(wg, bg, device="cpu", ln=norm)
+    perm = ops.geglu_perm(64)
+    refg = (F.layer_norm(x, (C,), norm.weight, norm.bias, norm.eps) @ wg.t() + bg)[:, perm]
+    assert (emulate(pg, x) - refg).abs().max() <= 2e-2 * refg.abs().max()
+    pc = ops.pack_linear_cat([w, w * 0.5], device="cpu", ln=norm)
+    assert pc.N == 2 * N and pc.bias is not None and torch.allclose(pc.bias[N:2 * N], (w * 0.5) @ norm.bias, atol=1e-6)
+    assert ops.pack_linear(w, b, device="cpu").colsum is None
+
+
+def test_video_unet_survives_deepcopy_and_pickle():
+    """the per-thread table of the batched emb_layers projection must not make the module un-copyable (EMA copies, torch.save)."""
+    import copy
+    import pickle
+    from vista_amd.config import unet_kwargs
+    from vista_amd.modules.diffusionmodules.video_model import VideoUNet
+    net = VideoUNet(**unet_kwargs(64))
+    twin = copy.deepcopy(net)
+    assert twin._emb_tls is not net._emb_tls and all(m._emb_src[0] is twin._emb_tls for m in twin._emb_blocks)
+    again = pickle.loads(pickle.dumps(net))
+    assert all(m._emb_src[0] is again._emb_tls for m in again._emb_blocks)
+    assert [k for k in again.state_dict()] == [k for k in net.state_dict()]

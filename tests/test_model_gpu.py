@@ -209,7 +209,7 @@ def test_sampler_full_50_step_schedule_vs_oracle():
     """The WHOLE 50-step EDM schedule end to end (VERDICT r1 missing #6; the longest chain before was 10 steps): 64-channel network,
     T=5, latent 16x32, VanillaCFG 2.5, fused path, against the CPU oracle's 50-step run (computed here, ~1 min on the host).
     Each step is a contraction towards the denoised estimate (x <- x + (sigma_next/sigma - 1)(x - D(x))), so per-step bf16 noise does
-    not grow without bound; stated tolerance rel-L2 <= 6e-2, measured value appended to gpurun_out/parity_50step.json."""
+    not grow without bound (measured 8.2e-3, below one forward's 1.3e-2); stated tolerance rel-L2 <= 2.5e-2, measured value appended to gpurun_out/parity_50step.json."""
     import json
     from oracle import vista_oracle as O
     from vista_amd import synth
@@ -233,4 +233,4 @@ def test_sampler_full_50_step_schedule_vs_oracle():
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
         json.dump({"steps": steps, "rel_l2": r}, open(os.path.join(d, "parity_50step.json"), "w"))
-    assert torch.isfinite(got).all() and r <= 6e-2 and torch.equal(got[0], w["cond_frame"][0])
+    assert torch.isfinite(got).all() and r <= 2.5e-2 and torch.equal(got[0], w["cond_frame"][0])
