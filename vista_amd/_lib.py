@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvista_hip.so")
+# VISTA_HIP_LIB: A/B tooling only (tools/build_rev.sh builds the library of another git revision next to the in-tree one so that two
+# kernel versions can be timed on the SAME box in one call); the product always loads the in-tree build.
+LIB_PATH = os.environ.get("VISTA_HIP_LIB") or os.path.join(_HERE, "lib", "libvista_hip.so")
 
 _vp = C.c_void_p
 _i32 = C.c_int32

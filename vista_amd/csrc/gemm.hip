@@ -56,9 +56,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     // split-K (small-M problems): workgroup = (K slice, tile), K slice as the slow index so neighbours still share weight tiles
     const int ntiles = tilesM * tilesN;
     // PERSIST (GEGLU kernels): a launch of 256 workgroups walks the tile list with stride gridDim.x instead of one workgroup per tile: no
-    // workgroup drain / dispatch between tiles, and the next tile's first DMA overlaps the previous tile's store drain (+3-6 % on the
-    // GEGLU shapes, whose gelu epilogue is the longest; neutral to -3 % on the other epilogues, which keep one workgroup per tile --
-    // profiles/r02_gemm_sweep_persistent_experiment.jsonl). No state is carried across tiles except the loop counter; gridDim.x is a
+    // workgroup drain / dispatch between tiles, and the next tile's first DMA overlaps this tile's store drain: +3-6 % on the GEGLU shapes
+    // (longest epilogue of the family), neutral to -3 % on the other epilogues, which keep one workgroup per tile
+    // (profiles/r02_gemm_sweep_persistent_experiment.jsonl). Also staging the next tile's first K-step BEFORE the gelu epilogue (two
+    // statistics tables, addresses formed on the fly) was correct but measured -1..-2.5 % in a same-box A/B (profiles/r02_ab_notes.txt):
+    // the per-tile overhead is the epilogue itself, not the prologue's memory round trip. No state is carried across tiles except the loop counter; gridDim.x is a
     // multiple of 8, so a workgroup's tiles stay in its XCD's range of the remap.
     const int total_wg = ntiles * ksplit;
     int bid = blockIdx.x;
@@ -275,13 +277,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     const int nk = kt1;
     // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
     // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
+    float2* const lnrow_cur = (float2*)(smem + LN_OFF);
     dma_tile(kt0, kt0 & 1);
     if (p.ln_stats != nullptr) {
         // row statistics of this tile's activation rows -> LDS. Issued AFTER the first tile's DMA so that both HBM round trips are in
-        // flight together (the other order serialised them: +1.5 us per tile); visible to every wave after the barrier below.
+        // flight together; visible to every wave after the barrier below.
         for (int r = tid; r < BM; r += NT) {
             const int m = m0 + r;
-            ((float2*)(smem + LN_OFF))[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
+            lnrow_cur[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
         }
     }
     __syncthreads();
@@ -304,8 +307,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             continue;  // (split-K launches are never persistent: one slice-tile per workgroup)
         }
     }
-    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn,
-                                                p.ln_stats != nullptr ? (const float2*)(smem + LN_OFF) : nullptr);
+    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr);
     if (PERSIST && bid + (int)gridDim.x < total_wg) __syncthreads();  // the next tile rewrites the LDS row-statistics table and stage 0
   } while (PERSIST && (bid += gridDim.x) < total_wg);
 }

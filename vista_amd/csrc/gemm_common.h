@@ -62,8 +62,8 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
             if (m >= p.M) continue;  // both lanes of a row (l31, l31 + 32) leave together
             const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
             const float* rv2 = rowvec2 ? rowvec2 + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
-            float mu = 0.f, rs = 1.f;
-            if (lnrow) { const float2 t = lnrow[m - m0]; mu = t.x; rs = t.y; }
+            float nrm = 0.f, rs = 1.f;
+            if (lnrow) { const float2 t = lnrow[m - m0]; rs = t.y; nrm = -t.x * t.y; }
             float ssum = 0.f, qsum = 0.f;  // row sums of the bf16-rounded outputs this lane stores (rowstat_out)
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
@@ -76,13 +76,13 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
-                    if (lnrow) {
+                    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (bias) b = *(const float4*)(bias + n);
+                    if (lnrow) {  // rstd*(acc - mean*colsum) + bias as two fmas per value: nrm = -rstd*mean is per row
                         const float4 c = *(const float4*)(lncs + n);
-                        v[0] = rs * (v[0] - mu * c.x); v[1] = rs * (v[1] - mu * c.y);
-                        v[2] = rs * (v[2] - mu * c.z); v[3] = rs * (v[3] - mu * c.w);
-                    }
-                    if (bias) {
-                        const float4 b = *(const float4*)(bias + n);
+                        v[0] = fmaf(rs, v[0], fmaf(nrm, c.x, b.x)); v[1] = fmaf(rs, v[1], fmaf(nrm, c.y, b.y));
+                        v[2] = fmaf(rs, v[2], fmaf(nrm, c.z, b.z)); v[3] = fmaf(rs, v[3], fmaf(nrm, c.w, b.w));
+                    } else if (bias) {
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                     if (rv) {
@@ -142,8 +142,8 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
         for (int fj = 0; fj < FY; ++fj) {
             const int m = m0 + wm * MW + fj * 32 + l31;
             if (m >= p.M) continue;
-            float mu = 0.f, rs = 1.f;
-            if (lnrow) { const float2 t = lnrow[m - m0]; mu = t.x; rs = t.y; }
+            float nrm = 0.f, rs = 1.f;
+            if (lnrow) { const float2 t = lnrow[m - m0]; rs = t.y; nrm = -t.x * t.y; }
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 const int nfrag = n0 + wn * NW + fi * 32;  // first packed row of the fragment
@@ -157,15 +157,19 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     float a[4], gt[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] = acc[fi][fj][4 * g + e]; gt[e] = acc[fi][fj][4 * (g + 2) + e]; }
-                    if (lnrow) {
+                    float4 ba = make_float4(0.f, 0.f, 0.f, 0.f), bg = ba;
+                    if (bias) {
+                        ba = *(const float4*)(bias + np);
+                        bg = *(const float4*)(bias + np + 16);
+                    }
+                    if (lnrow) {  // rstd*(acc - mean*colsum) + bias as two fmas per value
                         const float4 ca = *(const float4*)(lncs + np);
                         const float4 cg = *(const float4*)(lncs + np + 16);
-                        a[0] = rs * (a[0] - mu * ca.x); a[1] = rs * (a[1] - mu * ca.y); a[2] = rs * (a[2] - mu * ca.z); a[3] = rs * (a[3] - mu * ca.w);
-                        gt[0] = rs * (gt[0] - mu * cg.x); gt[1] = rs * (gt[1] - mu * cg.y); gt[2] = rs * (gt[2] - mu * cg.z); gt[3] = rs * (gt[3] - mu * cg.w);
-                    }
-                    if (bias) {
-                        const float4 ba = *(const float4*)(bias + np);
-                        const float4 bg = *(const float4*)(bias + np + 16);
+                        a[0] = fmaf(rs, a[0], fmaf(nrm, ca.x, ba.x)); a[1] = fmaf(rs, a[1], fmaf(nrm, ca.y, ba.y));
+                        a[2] = fmaf(rs, a[2], fmaf(nrm, ca.z, ba.z)); a[3] = fmaf(rs, a[3], fmaf(nrm, ca.w, ba.w));
+                        gt[0] = fmaf(rs, gt[0], fmaf(nrm, cg.x, bg.x)); gt[1] = fmaf(rs, gt[1], fmaf(nrm, cg.y, bg.y));
+                        gt[2] = fmaf(rs, gt[2], fmaf(nrm, cg.z, bg.z)); gt[3] = fmaf(rs, gt[3], fmaf(nrm, cg.w, bg.w));
+                    } else if (bias) {
                         a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
                         gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
                     }
