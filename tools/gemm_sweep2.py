@@ -31,7 +31,7 @@ def timeit(fn, iters=10):
 
 
 def main():
-    flags = [0]  # the experiment bits of this sweep were measured and removed (profiles/r02_gemm_sweep_*experiment.jsonl)
+    flags = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,8".split(","))]  # ops.TILE_FLAGS values to compare
     N = 50
     rn = lambda *s: torch.randn(*s, device="cuda")  # noqa: E731
     for C, H, W in ((320, 72, 128), (640, 36, 64), (1280, 18, 32)):
@@ -56,9 +56,9 @@ def main():
             best = {}
             for _ in range(3):
                 for f in flags:
-                    pass
+                    ops.TILE_FLAGS = f
                     best[f] = min(best.get(f, 1e9), timeit(fn))
-            pass
+            ops.TILE_FLAGS = 0
             print(json.dumps({"level_C": C, "kind": name, "M": M, "TFLOPs_by_flags": {str(f): round(flop / ms / 1e9) for f, ms in best.items()},
                               "ms_by_flags": {str(f): round(ms, 4) for f, ms in best.items()}}), flush=True)
         del x, res, h4, cases
