@@ -22,7 +22,7 @@ enum { VK_EPI_LINEAR = 0, VK_EPI_GEGLU = 1, VK_EPI_TRANS = 2 };
 
 typedef struct VkGemmDesc {
     const void* A;       /* bf16 activations: [M][lda] (DENSE) or NHWC source image stack (conv modes)            */
-    const void* Wt;      /* bf16 weights [pad(N)][K] (pad: multiple of 256 and >= ceil320(N)), K contiguous; conv: [Cout][tap][Cin]                    */
+    const void* Wt;      /* bf16 weights [pad(N)][K] (pad: multiple of 256 and >= ceil320(N)), K contiguous; conv: [Cout][Cin/64][tap][64]                    */
     void* out;           /* bf16 or f32 [M][ldc]; EPI_TRANS: bf16 [M/S][N][S]                                     */
     const float* bias;   /* [ceil256(N)] f32 or NULL (EPI_GEGLU: in packed row order)                             */
     const float* rowvec; /* f32 [M/rows_per_vec][ldv] added per image, or NULL                                    */

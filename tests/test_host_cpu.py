@@ -160,12 +160,18 @@ def test_weight_packing_layouts_on_cpu():
     assert pg.geglu and pg.N == 2 * nout and pg.K == K and pg.wt.shape[0] == 320  # rows padded so that every block tile (<= 320 wide) reads whole tiles
     assert torch.equal(pg.wt[:2 * nout].float(), w[perm].to(torch.bfloat16).float()) and pg.wt[2 * nout:].abs().sum() == 0
     assert torch.equal(pg.bias[:2 * nout], b[perm])
-    # conv3x3: [Cout][ky][kx][Cin padded to 64]
+    # conv3x3: [Cout][Cin slab of 64][ky][kx][64] (all taps of one channel slab on consecutive K-steps), Cin zero-padded to 64
     wc = torch.randn(8, 3, 3, 3)
     pc = ops.pack_conv3x3(wc, None, device="cpu")
     assert pc.N == 8 and pc.K == 9 * 64
-    v = pc.wt[:8].float().view(8, 3, 3, 64)
+    v = pc.wt[:8].float().view(8, 3, 3, 64)  # one slab: [Cout][ky][kx][64]
     assert torch.equal(v[..., :3], wc.permute(0, 2, 3, 1).to(torch.bfloat16).float()) and v[..., 3:].abs().sum() == 0
+    w2 = torch.randn(4, 128, 3, 3)           # two slabs
+    p2 = ops.pack_conv3x3(w2, None, device="cpu").wt[:4].float().view(4, 2, 3, 3, 64)
+    assert torch.equal(p2[:, 1, 2, 0], w2[:, 64:, 2, 0].to(torch.bfloat16).float())
+    wt3 = torch.randn(4, 128, 3, 1, 1)
+    p3 = ops.pack_conv_t3(wt3, None, device="cpu").wt[:4].float().view(4, 2, 3, 64)
+    assert torch.equal(p3[:, 1, 0], wt3[:, 64:, 0, 0, 0].to(torch.bfloat16).float())
     # odd Cout is rounded up to the 4-column epilogue quad with zero rows / bias
     pl = ops.pack_linear(torch.randn(3, 64), torch.randn(3), device="cpu")
     assert pl.N == 4 and pl.wt[3:].abs().sum() == 0 and pl.bias[3:].abs().sum() == 0

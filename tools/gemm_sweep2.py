@@ -31,7 +31,7 @@ def timeit(fn, iters=10):
 
 
 def main():
-    flags = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0,8".split(","))]  # ops.TILE_FLAGS values to compare
+    flags = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0".split(","))]  # experiment bits (attribute ops.TILE_FLAGS, honoured only by builds that carry an experiment)
     N = 50
     rn = lambda *s: torch.randn(*s, device="cuda")  # noqa: E731
     for C, H, W in ((320, 72, 128), (640, 36, 64), (1280, 18, 32)):

@@ -17,7 +17,9 @@ for r in rows:
     k = r[ki]
     if sub and sub not in k:
         continue
-    k = k.split("(")[0][-60:]
+    import re
+    m = re.search(r"(\w+_kernel)", k)
+    k = m.group(1) if m else k.split("(")[0][-60:]
     e = agg.setdefault(k, {})
     e.setdefault(r[ci], []).append(r[vi])
 for k, e in agg.items():

@@ -6,7 +6,10 @@
 //                                            (openaimodel.py:198,232 ResBlock convs; :136 Downsample; :100-102 Upsample)
 //   TEMPORAL3  3x1x1 conv over frames, pad (1,0,0)   (video_model.py:38-52 time_stack)
 //   CONV3D     3x3x3 conv over (frames, H, W), pad 1 (temporal VAE decoder: autoencoding/temporal_ae.py:24-37,82-87)
-// W is [Npad][K] with K contiguous (= nn.Linear.weight layout; conv weights are packed [Cout][tap][Cin]).
+// W is [Npad][K] with K contiguous (= nn.Linear.weight layout; conv weights are packed [Cout][Cin/64][tap][64]: the K-loop walks all
+// taps of one 64-channel slab before the next slab, so a tile re-reads its input rows on CONSECUTIVE K-steps and they hit the XCD's L2.
+// With the tap-major order of round 1 ([Cout][tap][Cin]) the re-read came 5..20 K-steps x 32 workgroups later, missed the 4 MiB L2 and
+// went through the fabric: 2.65 GB fetched per level-0 conv launch for 0.3 GB of input (rocprofv3 FETCH_SIZE, profiles/r02_pmc_traffic.txt).
 //
 // Tiling (template): block tile BM x BN x 64 with WM x WN waves, each wave FM x FN MFMA 32x32x16 bf16 tiles, fp32 accumulate.
 // Every layout keeps a wave at <= 128 VGPRs, i.e. FOUR waves per SIMD: co-resident waves, not a hand-built phase schedule, are
@@ -131,8 +134,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
 
     const int nk_all = p.K / BK;
     const int kt0 = (int)((long long)kslice * nk_all / ksplit), kt1 = (int)((long long)(kslice + 1) * nk_all / ksplit);
-    // (tap, channel offset) of the next K-step to stage, for the conv loaders: starts at this workgroup's first K-step
-    int tap = (AMODE == AMODE_DENSE) ? 0 : (kt0 * BK) / p.Cin, c0 = (AMODE == AMODE_DENSE) ? 0 : (kt0 * BK) % p.Cin;
+    // (tap, channel offset) of the next K-step to stage, for the conv loaders: K-step kt = (channel slab kt / NTAPS, tap kt % NTAPS);
+    // starts at this workgroup's first K-step
+    constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : (AMODE == AMODE_CONV3D) ? 27 : 1;
+    int tap = (AMODE == AMODE_DENSE) ? 0 : kt0 % NTAPS, c0 = (AMODE == AMODE_DENSE) ? 0 : (kt0 / NTAPS) * BK;
 
     // direct global -> LDS staging of tile kt into `stage` (one 1-KiB global_load_lds_dwordx4 per wave and 8-row group)
     auto dma_tile = [&](int kt, int stage) {
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         } else if (AMODE == AMODE_CONV3D) {
-            // tap = kt*9 + ky*3 + kx; zero padding in time (clip ends) and space (video_model-style Conv3d(k=3, pad=1):
+            // tap = kt3*9 + ky*3 + kx; zero padding in time (clip ends) and space (video_model-style Conv3d(k=3, pad=1):
             // vwm/modules/autoencoding/temporal_ae.py:24-37,82-87)
             const int kt3 = tap / 9, r9 = tap - kt3 * 9;
             const int ky = r9 / 3, kx = r9 - ky * 3;
@@ -207,8 +212,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         }
-        c0 += BK;
-        if (c0 >= p.Cin) { c0 = 0; ++tap; }
+        if (++tap == NTAPS) { tap = 0; c0 += BK; }
     };
 
     f32x16_t acc[FX][FY];

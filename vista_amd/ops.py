@@ -127,18 +127,25 @@ def pack_geglu(weight, bias, device="cuda", ln=None):
     return _finish_pack(w[perm], b[perm], device, geglu=True, ln=None if ln is None else _ln_tuple(ln))
 
 
+def _slab_major(w):
+    """[Cout][taps][Cin] (Cin % 64 == 0) -> [Cout][Cin/64][taps][64] flattened along K: the implicit-GEMM K-loop visits all taps of one
+    64-channel slab on consecutive K-steps (the input rows a tile re-reads then sit in L2; csrc/gemm.hip header)."""
+    cout, taps, cin = w.shape
+    return w.reshape(cout, taps, cin // 64, 64).permute(0, 2, 1, 3).reshape(cout, taps * cin)
+
+
 def pack_conv3x3(weight, bias=None, cin_pad=None, device="cuda"):
-    """nn.Conv2d weight [Cout][Cin][3][3] -> [Cout][ky][kx][Cin(_pad)]."""
+    """nn.Conv2d weight [Cout][Cin][3][3] -> [Cout][Cin(_pad)/64][ky][kx][64]."""
     w = weight.detach().float().permute(0, 2, 3, 1).contiguous()  # Cout, ky, kx, Cin
     cout, _, _, cin = w.shape
     cp = cin_pad or ceil_to(cin, 64)
     if cp != cin:
         w = torch.nn.functional.pad(w, (0, cp - cin))
-    return _finish_pack(w.reshape(cout, 9 * cp), None if bias is None else bias.detach().float(), device)
+    return _finish_pack(_slab_major(w.reshape(cout, 9, cp)), None if bias is None else bias.detach().float(), device)
 
 
 def pack_conv_t3(weight, bias=None, device="cuda", cin_pad=None):
-    """nn.Conv3d weight [Cout][Cin][3][1][1] -> [Cout][kt][Cin(_pad)]."""
+    """nn.Conv3d weight [Cout][Cin][3][1][1] -> [Cout][Cin(_pad)/64][kt][64]."""
     w = weight.detach().float()[:, :, :, 0, 0].permute(0, 2, 1).contiguous()
     cout, _, cin = w.shape
     if cin_pad and cin_pad != cin:
@@ -146,7 +153,7 @@ def pack_conv_t3(weight, bias=None, device="cuda", cin_pad=None):
         cin = cin_pad
     if cin % 64:
         raise ValueError("temporal conv needs Cin % 64 == 0")
-    return _finish_pack(w.reshape(cout, 3 * cin), None if bias is None else bias.detach().float(), device)
+    return _finish_pack(_slab_major(w), None if bias is None else bias.detach().float(), device)
 
 
 # ---------------------------------------------------------------------------------------------- GEMM family
@@ -353,13 +360,13 @@ def conv_t3(x, pw, T, S, *, out=None, out_f32=False, rowvec=None, res1=None, res
 
 
 def pack_conv3d(weight, bias=None, device="cuda", cin_pad=None):
-    """nn.Conv3d weight [Cout][Cin][3][3][3] -> [Cout][kt][ky][kx][Cin(_pad)] (temporal VAE decoder)."""
+    """nn.Conv3d weight [Cout][Cin][3][3][3] -> [Cout][Cin(_pad)/64][kt][ky][kx][64] (temporal VAE decoder)."""
     w = weight.detach().float().permute(0, 2, 3, 4, 1).contiguous()  # Cout, kt, ky, kx, Cin
     cout, _, _, _, cin = w.shape
     cp = cin_pad or ceil_to(cin, 64)
     if cp != cin:
         w = torch.nn.functional.pad(w, (0, cp - cin))
-    return _finish_pack(w.reshape(cout, 27 * cp), None if bias is None else bias.detach().float(), device)
+    return _finish_pack(_slab_major(w.reshape(cout, 27, cp)), None if bias is None else bias.detach().float(), device)
 
 
 def conv3d(x, pw, T, H, W, *, out=None, out_f32=False, res1=None, res2=None, alpha=1.0, beta=0.0):
