@@ -164,22 +164,35 @@ class MemoryEfficientCrossAttention(nn.Module, Packable):
             self.v_adapter_action_control = zero_module(Linear(128 * 19, inner_dim, bias=False))
 
     def _pack(self, dev):
-        pk = {"out": ops.pack_linear(self.to_out[0].weight, self.to_out[0].bias, dev)}
-        if not self.is_self:
-            ws = [self.to_v.weight]
-            if self.action_control:
-                ws.append(self.v_adapter_action_control.weight)
-            pk["vctx"] = ops.pack_linear(torch.cat([w.detach().float() for w in ws], 1), None, dev)  # [to_v | v_adapter] along K
-        return pk
+        if self.is_self:
+            return {"out": ops.pack_linear(self.to_out[0].weight, self.to_out[0].bias, dev)}
+        w, b = self.context_map()
+        return {"ctx": ops.pack_linear(w, b, dev)}
+
+    def context_map(self):
+        """Cross-attention against a ONE-token context is a single affine map of that token: softmax over one key == 1, so the output is
+        to_out(to_v(ctx) + v_adapter(ctx_act)) for every query (attention.py:341-353,400-421), and with no non-linearity in between
+        that is ctx @ (W_out [W_v | W_va])^T + b_out. Returns the composed (query_dim, context_dim [+ 2432]) weight and the bias (fp32)."""
+        ws = [self.to_v.weight]
+        if self.action_control:
+            ws.append(self.v_adapter_action_control.weight)
+        wv = torch.cat([w.detach().float() for w in ws], 1)                      # (inner, ctx_width): [to_v | v_adapter] along K
+        return self.to_out[0].weight.detach().float() @ wv, self.to_out[0].bias.detach().float()
 
     def context_vector(self, ctx):
-        """Cross-attention against a ONE-token context: returns to_out(v(ctx)) as (n_ctx, query_dim) f32.
-        ctx: (n_ctx, context_dim [+ 2432]) bf16."""
+        """attn2(norm2(x), ctx) for a ONE-token context: (n_ctx, query_dim) f32, constant over the queries. ctx: (n_ctx, ctx_width) bf16.
+        Inside a VideoUNet forward the value comes from the UNet's one batched GEMM over every cross-attention of the network (a
+        column slice of its table); standalone, from this layer's own composed weight."""
+        src = getattr(self, "_ctx_src", None)  # (per-thread table holder, key, column offset) when a VideoUNet owns this layer
+        if src is not None:
+            tab = src[0].table
+            t = tab.get(src[1]) if tab is not None else None
+            if t is not None and t.shape[0] == ctx.shape[0]:
+                return t[:, src[2]:src[2] + self.query_dim]
         pk = self.packed()
-        if ctx.shape[-1] != pk["vctx"].K:
-            raise ValueError(f"context width {ctx.shape[-1]} does not match to_v (+ action adapter) width {pk['vctx'].K}")
-        v = ops.linear(ctx, pk["vctx"])
-        return ops.linear(v, pk["out"], out_f32=True)
+        if ctx.shape[-1] != pk["ctx"].K:
+            raise ValueError(f"context width {ctx.shape[-1]} does not match to_v (+ action adapter) width {pk['ctx'].K}")
+        return ops.linear(ctx, pk["ctx"], out_f32=True)
 
 
 class BasicTransformerBlock(nn.Module, Packable):

@@ -143,6 +143,7 @@ class ResBlock(TimestepBlock, Packable):
         # (n_img, Cout): `emb_layers(emb)[..., None, None]`; skip_t_emb adds zeros (openaimodel.py:268-269)
         src = getattr(self, "_emb_src", None)  # (thread-local table, column offset, width) when a VideoUNet owns this block
         table = getattr(src[0], "table", None) if src is not None else None
+        table = table.get("emb") if table is not None else None
         if self.emb_layers is None:
             emb_out = None
         elif table is not None and table.shape[0] == n_img:

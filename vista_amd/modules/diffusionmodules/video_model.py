@@ -23,7 +23,8 @@ CIN_PAD = 64  # the 8 input channels are zero-padded to one 64-wide K-step of th
 
 
 class _ThreadTable:
-    """Per-thread slot for the batched emb_layers projection of the forward in flight (the multi-rank tests drive one model from
+    """Per-thread slot for the batched projections of the forward in flight (a dict: "emb" = every ResBlock's emb_layers output,
+    "ctx_s" / "ctx_t" = every spatial / temporal cross-attention's context vector (the multi-rank tests drive one model from
     several threads). Unlike threading.local it survives copy.deepcopy / pickling of the module that owns it (a fresh, empty table)."""
 
     def __init__(self):
@@ -233,6 +234,19 @@ class VideoUNet(nn.Module, Packable):
                 object.__setattr__(m, "_emb_src", (self._emb_tls, off, m.out_channels))
                 self._emb_blocks.append(m)
                 off += m.out_channels
+        # Likewise the 32 one-token cross-attentions (attn2 of every spatial / temporal transformer block): each is ONE affine map of the
+        # context token (MemoryEfficientCrossAttention.context_map), so all of a kind run as one GEMM over the row-concatenated maps
+        # (64 launches of 1..50-row GEMMs with K = 3456 per forward -> 2; they were 1.5 % of a single-GPU step and 7 % of an 8-GPU rank's).
+        from ..attention import BasicTransformerBlock
+        from ..video_attention import VideoTransformerBlock
+        self._ctx_layers = {"ctx_s": [], "ctx_t": []}
+        offs = {"ctx_s": 0, "ctx_t": 0}
+        for m in self.modules():
+            key = "ctx_s" if isinstance(m, BasicTransformerBlock) else ("ctx_t" if isinstance(m, VideoTransformerBlock) and m.has_cross else None)
+            if key is not None:
+                object.__setattr__(m.attn2, "_ctx_src", (self._emb_tls, key, offs[key]))
+                self._ctx_layers[key].append(m.attn2)
+                offs[key] += m.attn2.query_dim
 
     # ---- weights ----
     # No load_state_dict override: every Packable keys its packed weights on its parameters' version counters, so ANY load
@@ -246,6 +260,9 @@ class VideoUNet(nn.Module, Packable):
         ps = [p for seq in (self.time_embed, self.cond_time_stack_embed, self.label_emb, self.out) for p in seq.parameters()]
         for m in self._emb_blocks:
             ps += list(m.emb_layers.parameters())
+        for layers in self._ctx_layers.values():
+            for a in layers:
+                ps += [a.to_v.weight, a.to_out[0].weight, a.to_out[0].bias] + ([a.v_adapter_action_control.weight] if a.action_control else [])
         return ps
 
     def _pack(self, dev):
@@ -253,7 +270,11 @@ class VideoUNet(nn.Module, Packable):
             return (ops.pack_linear(seq[0].weight, seq[0].bias, dev), ops.pack_linear(seq[2].weight, seq[2].bias, dev))
         emb_w = torch.cat([m.emb_layers[1].weight.detach().float() for m in self._emb_blocks], 0)
         emb_b = torch.cat([m.emb_layers[1].bias.detach().float() for m in self._emb_blocks], 0)
-        return {"emb_cat": ops.pack_linear(emb_w, emb_b, dev),
+        ctx = {}
+        for key, layers in self._ctx_layers.items():
+            maps = [a.context_map() for a in layers]
+            ctx[key] = ops.pack_linear(torch.cat([w for w, _ in maps], 0), torch.cat([b for _, b in maps], 0), dev)
+        return {"emb_cat": ops.pack_linear(emb_w, emb_b, dev), **ctx,
                 "time_embed": mlp(self.time_embed), "cond": mlp(self.cond_time_stack_embed), "label": mlp(self.label_emb[0]),
                 "out": ops.pack_conv3x3(self.out[2].weight, self.out[2].bias, device=dev)}
 
@@ -314,7 +335,10 @@ class VideoUNet(nn.Module, Packable):
             ctx = shard.take_local_rows(ctx)
         kw = dict(frame_idx=frame_idx, num_frames=T, shard=shard, full=full)
 
-        self._emb_tls.table = ops.linear(emb_silu, pk["emb_cat"], out_f32=True)  # all emb_layers projections of this forward
+        clip_ctx = (ctx if full is None else full["ctx"]).view(n_img // T, T, -1)[:, 0]  # context[::T]: first frame of every clip
+        self._emb_tls.table = {"emb": ops.linear(emb_silu, pk["emb_cat"], out_f32=True),   # all emb_layers projections of this forward
+                               "ctx_s": ops.linear(ctx, pk["ctx_s"], out_f32=True),          # all spatial cross-attention context vectors
+                               "ctx_t": ops.linear(clip_ctx, pk["ctx_t"], out_f32=True)}     # all temporal ones (one per clip)
         try:
             hs = []
             h = tokens
