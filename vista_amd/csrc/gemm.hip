@@ -77,7 +77,23 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     const int l31 = lane & 31, lh = lane >> 5;
     const int lin = xcd_remap(bid, total_wg);
     const int kslice = lin / ntiles, logical = lin - kslice * ntiles;
-    const int tn = logical % tilesN, tm = logical / tilesN;
+    // Tile order. Narrow outputs (tilesN < 8): column tile fastest -- the few column tiles of a row tile run together, share its
+    // activation rows in L2, and the whole weight matrix is L2-resident anyway. Wide outputs (GEGLU: 10-40 column tiles, weights of
+    // 6-26 MB against a 4 MiB L2): panels of GM = 8 row tiles, row tile fastest inside a panel, so the 32 workgroups an XCD runs at a
+    // time form an 8 x 4 block that streams 8 activation + 4 weight K-slices per step instead of 1 + 32 (rocprofv3 FETCH_SIZE of the
+    // level-2 GEGLU: 3.06 GB per launch with the column-fastest order = every tile re-streaming its weight tile through the fabric;
+    // 1.24 GB with the panels; same-box A/B +4-8 % at level 2, +0-2 % at level 1, -2-3 % at level 0 where it is therefore not used).
+    int tn, tm;
+    if (tilesN < 8 || (long long)p.N * p.K * 2 <= (3LL << 20)) {  // (weights that fit the L2 are re-read from it whatever the order: level-0 GEGLU)
+        tn = logical % tilesN;
+        tm = logical / tilesN;
+    } else {
+        constexpr int GM = 8;
+        const int panel = logical / (GM * tilesN), r = logical - panel * (GM * tilesN);
+        const int gm = (tilesM - panel * GM < GM) ? tilesM - panel * GM : GM;
+        tm = panel * GM + r % gm;
+        tn = r / gm;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const uint16_t* __restrict__ Ag = (const uint16_t*)p.A;
