@@ -26,7 +26,6 @@ def install():
         raise RuntimeError(f"reference tree not found at {REF_ROOT}")
     if "vwm" in sys.modules and getattr(sys.modules["vwm"], "_vista_shim", False):
         return
-    import torch
     import torch.nn.functional as F
 
     vwm = types.ModuleType("vwm")
