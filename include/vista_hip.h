@@ -78,6 +78,31 @@ int vk_gemm_rowstat_parts(const VkGemmDesc* d);
  * amode must be DENSE, epi LINEAR or GEGLU; the epilogue fields (bias, rowvec, res1/res2, alpha/beta, out_f32) as for bf16. */
 int vk_gemm_fp8(const VkGemmDesc* desc, const float* a_scale, const float* w_scale, int32_t k_real, void* stream);
 
+/* The same GEMM with the round-2 options (all optional; vk_gemm_fp8(d, a_scale, w_scale, k_real) == {a_scale, w_scale, k_real, 0...}):
+ *   a_mx / ld_mx     : MX block scales of the activations INSTEAD of a_scale: E8M0 bytes (2^(e-127)) [M][ld_mx], one per 32 consecutive
+ *                      K-elements, applied inside v_mfma_scale_f32_32x32x64_f8f6f4; ld_mx % 4 == 0 and ld_mx * 32 >= d->K.
+ *   mx_out / ld_mx_out: EPI_GEGLU only: write the gated output as MX fp8 -- d->out = e4m3 bytes [M][d->ldc], mx_out = E8M0 [M][ld_mx_out],
+ *                      one scale per 32 output columns, chosen in the epilogue (2^e >= max|h| / 448) -- so that the FeedForward's second
+ *                      GEMM (a_mx = this mx_out) needs no quantisation pass (attention.py:85-128). (N/2) % 32 == 0, ldc % 16 == 0.
+ * d->rowstat_out is honoured (vk_gemm_fp8_rowstat_parts sizes it). */
+typedef struct VkFp8Args {
+    const float* a_scale;
+    const float* w_scale;
+    int32_t k_real;
+    const void* a_mx;
+    int32_t ld_mx;
+    void* mx_out;
+    int32_t ld_mx_out;
+} VkFp8Args;
+int vk_gemm_fp8_mx(const VkGemmDesc* desc, const VkFp8Args* args, void* stream);
+int vk_gemm_fp8_rowstat_parts(const VkGemmDesc* d);
+
+/* LayerNorm fused with per-row dynamic fp8 quantisation: y = LN(x)*gamma + beta (as vk_layernorm_bf16), scale[r] = max|y[r]| / 448,
+ * q[r] = e4m3(y[r] / scale[r]) -- one pass, the normalised tensor is never written in bf16 (FeedForward input of the fp8 configuration:
+ * attention.py:524, video_attention.py:119-137). C % 8 == 0, C <= 1536. */
+int vk_layernorm_quant_fp8(const void* x, void* q, float* scale, const float* gamma, const float* beta, int32_t rows, int32_t C, float eps,
+                           void* stream);
+
 /* Per-row dynamic quantisation bf16 -> fp8 e4m3: scale[m] = max|x[m][:]| / 448, q = e4m3(x / scale). K % 8 == 0, K <= 5120. */
 int vk_quantize_rows_fp8(const void* x, void* q, float* scale, int32_t M, int32_t K, int64_t ldx, int64_t ldq, void* stream);
 

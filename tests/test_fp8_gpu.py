@@ -100,6 +100,124 @@ def test_geglu_fp8():
     assert out.shape == (M, nout) and (e <= 2e-2 * ref.pow(2).mean().sqrt() + 1.6e-2 * ref.abs()).all()
 
 
+def _mx_deq(q_u8, s_u8):
+    """MX fp8 -> f32: e4m3 codes x 2^(e - 127) per 32 consecutive columns."""
+    v = q_u8.cpu().view(torch.float8_e4m3fn).float()
+    sc = torch.exp2(s_u8.cpu().float() - 127.0)
+    return v * sc.repeat_interleave(32, 1)
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (257, 640), (129, 1280), (64, 64)])
+def test_layernorm_quant_fp8(rows, C):
+    """LayerNorm + per-row quantisation in one kernel == vk_layernorm's function followed by vk_quantize_rows_fp8's."""
+    ops = _ops()
+    x = (rnd(rows, C) * torch.logspace(-1, 1, rows)[:, None] + 0.7).to(BF16).cuda()
+    norm = torch.nn.LayerNorm(C).cuda()
+    with torch.no_grad():
+        norm.weight.copy_(rnd(C, seed=4) * 0.3 + 1.0)
+        norm.bias.copy_(rnd(C, seed=5) * 0.2)
+    q, s = ops.layernorm_quant_fp8(x, norm)
+    y = torch.nn.functional.layer_norm(x.float(), (C,), norm.weight, norm.bias, norm.eps).cpu()
+    want_s = y.abs().amax(1) / 448.0
+    assert torch.allclose(s.cpu(), want_s, rtol=2e-5, atol=0)
+    got = q.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(got).all()
+    want_q = (y / want_s[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    diff = (got - want_q).abs()
+    assert (diff > 0).float().mean().item() < 5e-3 and (diff <= want_q.abs() * 0.13 + 2 ** -9).all()
+    assert rel_l2(got * s.cpu()[:, None], y) < 4e-2
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3])
+@pytest.mark.parametrize("M,K,nout", [(520, 320, 1280), (4608, 640, 2560), (130, 64, 256)])
+def test_geglu_fp8_mx_output(M, K, nout, cfg):
+    """GEGLU epilogue quantising its own output to MX fp8: per (row, 32-column block) the scale is the smallest power of two with
+    max|h| / 2^e < 448, and every element is the e4m3 rounding of h / 2^e (<= 2^-4 relative, or half a subnormal step 2^-10 * 2^e)."""
+    ops = _ops()
+    x = rnd(M, K).to(BF16).cuda()
+    w = rnd(2 * nout, K, scale=K ** -0.5, seed=1)
+    b = rnd(2 * nout, seed=2)
+    pw = ops.pack_geglu_fp8(w, b)
+    xq, xs = ops.quantize_rows_fp8(x)
+    ops.TILE_CFG = cfg
+    try:
+        h8, hs = ops.linear_fp8(xq, xs, pw, mx_out=True)
+        hb = ops.linear_fp8(xq, xs, pw)  # the bf16-output kernel on the same operands
+    finally:
+        ops.TILE_CFG = 0
+    assert h8.shape == (M, nout) and h8.dtype == torch.uint8 and hs.shape == (M, nout // 32)
+    perm = ops.geglu_perm(nout)
+    wd = torch.empty(2 * nout, K)
+    wd[perm] = pw.wt[:2 * nout, :K].cpu().view(torch.float8_e4m3fn).float() * pw.scale[:2 * nout].cpu()[:, None]
+    h = deq(xq, xs) @ wd.t() + b
+    ref = h[:, :nout] * torch.nn.functional.gelu(h[:, nout:])
+    codes = h8.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(codes).all()
+    cmax = codes.abs().view(M, nout // 32, 32).amax(2)
+    assert (cmax <= 448).all() and (cmax >= 208).all(), "block scale is not the tightest power of two"  # 224 less one e4m3 step
+    two_e = torch.exp2(hs.cpu().float() - 127.0).repeat_interleave(32, 1)
+    e = (_mx_deq(h8, hs) - ref).abs()
+    assert (e <= (2 ** -4) * 1.02 * ref.abs() + two_e * 2 ** -10 + 2e-3 * ref.pow(2).mean().sqrt()).all()
+    assert rel_l2(_mx_deq(h8, hs), hb) < 4e-2
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 1280), (4608, 640, 2560), (777, 1280, 5120), (130, 64, 256)])
+def test_linear_fp8_mx_activations(M, N, K, cfg):
+    """Out-projection consuming MX block-scaled activations (scales applied inside v_mfma_scale_f32_32x32x64_f8f6f4): exact against
+    the dequantised operands, for block scales spread over 2^-8 .. 2^6 so that a wrong block / lane / op_sel mapping cannot hide."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 100).clamp(-448, 448).to(torch.float8_e4m3fn)
+    a8 = a.view(torch.uint8).cuda()
+    sc = torch.randint(119, 134, (M, K // 32), generator=g, dtype=torch.uint8).cuda()
+    w = rnd(N, K, scale=K ** -0.5, seed=1)
+    b = rnd(N, seed=2)
+    pw = ops.pack_linear_fp8(w, b)
+    r1 = rnd(M, N, seed=3).to(BF16).cuda()
+    ops.TILE_CFG = cfg
+    try:
+        out, st = ops.linear_fp8(a8, None, pw, a_mx=sc, res1=r1, emit_stats=True)
+    finally:
+        ops.TILE_CFG = 0
+    wd = pw.wt[:N, :K].cpu().view(torch.float8_e4m3fn).float() * pw.scale[:N].cpu()[:, None]
+    ref = _mx_deq(a8, sc) @ wd.t() + b + r1.float().cpu()
+    e = (out[:, :N].float().cpu() - ref).abs()
+    assert (e <= 2e-2 * ref.pow(2).mean().sqrt() + 1.6e-2 * ref.abs()).all(), f"max err {e.max().item()} rms {ref.pow(2).mean().sqrt().item()}"
+    o = out[:, :N].float()
+    tot = st.t.sum(0)
+    assert torch.allclose(tot[:, 0], o.sum(1), rtol=1e-3, atol=1e-2 * o.abs().mean().item() * N ** 0.5)
+    assert torch.allclose(tot[:, 1], o.pow(2).sum(1), rtol=1e-3)
+    with pytest.raises(ValueError):
+        ops.linear_fp8(a8, torch.ones(M, device="cuda"), pw, a_mx=sc)  # one kind of activation scale
+
+
+@pytest.mark.parametrize("dim,M", [(320, 1200), (1280, 300)])
+def test_feedforward_fp8_no_quantisation_pass(dim, M):
+    """FeedForward of config 5: LN+quant -> fp8 GEGLU (MX out) -> fp8 out-projection (MX in), vs the fp32 function. Re-stated tolerance
+    on the branch output (residual excluded): four e4m3 roundings in series -- x and W1 (3.6e-2 together, module docstring), the
+    value and the gate both carry that error into value*gelu(gate) (another ~3.6e-2), then h and W2 (2.6e-2 each):
+    sqrt(2 * 3.6^2 + 2 * 2.6^2) e-2 = 6.3e-2 expected, 6.5e-2 measured at dim 320 -> rel-L2 <= 8e-2."""
+    ops = _ops()
+    from vista_amd.modules import attention
+    ff = attention.FeedForward(dim, glu=True).cuda()
+    norm = torch.nn.LayerNorm(dim).cuda()
+    x = (rnd(M, dim) + 0.3).to(BF16).cuda()
+    attention.FP8["feedforward"] = True
+    try:
+        out, st = ff.forward_folded(x, None, None, norm, emit_stats=True)
+    finally:
+        attention.FP8["feedforward"] = False
+    with torch.no_grad():
+        lin = torch.nn.functional.linear
+        y = norm(x.float())
+        a, g = lin(y, ff.net[0].proj.weight, ff.net[0].proj.bias).chunk(2, -1)
+        ref = lin(a * torch.nn.functional.gelu(g), ff.net[2].weight, ff.net[2].bias)
+    assert rel_l2(out, ref) <= 8e-2
+    o = out.float()
+    assert torch.allclose(st.t.sum(0)[:, 0], o.sum(1), rtol=1e-3, atol=1e-2 * o.abs().mean().item() * dim ** 0.5)
+
+
 def test_fp8_rejects_bad_arguments():
     ops = _ops()
     pw = ops.pack_linear_fp8(rnd(64, 64), None)

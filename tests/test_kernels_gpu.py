@@ -221,6 +221,29 @@ def test_attn_spatial_spike_forces_rescale():
     close(o, _sdpa(q[None], k[None], v[None])[0], "attn spike", rtol=2e-2, arel=3e-2)
 
 
+@pytest.mark.parametrize("S", [512, 2304])
+@pytest.mark.parametrize("gain", [3.0, 12.0, 60.0])
+def test_attn_spatial_max_free_fast_path_falls_back(S, gain):
+    """The kernel takes the exponentials of a tile against the EXISTING softmax base without computing the tile's maximum and
+    validates the tile afterwards through its row sums (attention.hip, "max-free fast path"). Scores that jump far above the base
+    in a LATE tile must send that tile through the slow path: gain 3 stays within the threshold band, 12 exceeds it, 60 overflows
+    fp32 exp2 against the old base (|q|^2 ~ 64 -> 60*64/8*log2(e) ~ 690 octaves -> +inf row sums). Also a row block whose FIRST
+    tile is far BELOW everything that follows (the first base is useless), and all-equal scores."""
+    ops = _ops()
+    q = rnd(S, 64)
+    k = rnd(S, 64, seed=1)
+    v = rnd(S, 64, seed=2)
+    for j, row in enumerate(range(70, S, 197)):      # spikes spread over many tiles, each aimed at a different query row
+        k[row] = q[(37 * j + 5) % S] * gain
+    k[:64] = -q[300] * gain                           # query row 300: its first tile sits far below its later scores
+    k[S - 1] = q[300] * gain
+    q[11] = 0                                         # all scores equal: uniform softmax
+    vt = v.t().contiguous().view(1, 64, S)
+    o = ops.attn_spatial(q, k, vt, 1, 1, S)
+    assert torch.isfinite(o.float()).all()
+    close(o, _sdpa(q[None], k[None], v[None])[0], f"attn max-free S={S} gain={gain}", rtol=2e-2, arel=3e-2)
+
+
 @pytest.mark.parametrize("B,T,S,heads", [(2, 25, 40, 5), (1, 25, 144, 2), (2, 7, 9, 1), (1, 32, 16, 3)])
 def test_attn_temporal(B, T, S, heads):
     ops = _ops()

@@ -7,8 +7,15 @@
 // epilogue) with 128 fp8 K-elements per row and v_mfma_scale_f32_32x32x64_f8f6f4 (scale operands 0 = unscaled fp8 x fp8):
 // per K-step a wave issues the same number of MFMA cycles as the bf16 kernel for twice the FLOPs, and stages half the bytes
 // per FLOP through the LDS-DMA path that bounds the bf16 kernel.
-// Operand layout of the 32x32x64 instruction (probed, tools/probes/fp8_mfma_probe.hip): lane l holds row l&31 and the 32
-// consecutive k-bytes [32*(l>>5), +32) in 8 VGPRs; C/D layout is the bf16 32x32 one.
+// Operand layout of the 32x32x64 instruction (probed, tools/probes/fp8_mfma_probe.hip, tools/probes/mx_scale_probe.hip): lane l holds row
+// l&31; its VGPRs 0-3 are 16 k-bytes of the instruction's FIRST 32-element K-block and VGPRs 4-7 are 16 k-bytes of the SECOND (lanes r and
+// r+32 together hold both halves of each block); C/D layout is the bf16 32x32 one. Block scales (MX, E8M0 = 2^(e-127) per 32 K-elements):
+// the scale of (row r, block b) is byte op_sel of the scale VGPR of lane r + 32b. The fragment loader below therefore hands lane half
+// h the 16-B chunks (h, 2 + h) of each 64-byte K-slab: chunks (0,1) = block 0 and (2,3) = block 1 are 32 CONSECUTIVE k-bytes in memory.
+//
+// Two ways to scale the activations: per ROW (a_scale, applied to the accumulators after the K-loop: inputs quantised by
+// vk_quantize_rows_fp8 / vk_layernorm_quant_fp8) or per (row, 32-element block) in the MFMA itself (a_mx: the producer GEMM's epilogue
+// quantised its own output locally -- GEGLU with mx_out -- so no quantisation pass exists between the two FeedForward GEMMs).
 #include "gemm_common.h"
 
 namespace {
@@ -19,12 +26,29 @@ typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 __device__ uint4 g_zero16_f8;
 
 struct F8Args {
-    const float* a_scale;  // [M] per-row activation scale
+    const float* a_scale;  // [M] per-row activation scale, or NULL (then a_mx)
     const float* w_scale;  // [N padded] per-output-channel weight scale (GEGLU: in packed row order)
     int K;                 // real K (multiple of 16); p.K = weight row stride in bytes (multiple of 128, zero-filled past K)
+    const uint8_t* a_mx;   // E8M0 block scales of the activations, [M][ld_mx] bytes, one per 32 K-elements, or NULL
+    int ld_mx;
+    uint8_t* mx_out;       // EPI_GEGLU: E8M0 block scales of the fp8 output written to p.out ([M][ld_mx_out], one per 32 output columns), or NULL
+    int ld_mx_out;
 };
 
-template <int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
+// lower lane: the 16 output columns of fragment A; upper lane: those of fragment B (each lane holds columns {0-3, 8-11} + 4*lh of both)
+__device__ __forceinline__ uint4 widen_quads_fp8(uint32_t a_g0, uint32_t a_g1, uint32_t b_g0, uint32_t b_g1) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a_g0, b_g0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a_g1, b_g1, false, false);
+    return make_uint4(r0[0], r0[1], r1[0], r1[1]);
+}
+
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+
+template <int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, int FN>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp8_kernel(const VkGemmDesc p, const F8Args q) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;
@@ -94,16 +118,36 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
     const int xrow_off = A_BYTES + (xoff + l31) * 128, yrow_off = (yoff + l31) * 128;
 
     auto load_frag = [&](const char* rowp, int ks) {
-        const int c = ks * 4 + lh * 2;  // the lane's 32 k-bytes = logical chunks c, c+1 of the 128-byte row
+        const int c = ks * 4 + lh;  // lane half h holds chunk h of K-block 0 (VGPRs 0-3) and chunk 2+h of K-block 1 (VGPRs 4-7) of the slab
         const i32x4_t lo = *(const i32x4_t*)(rowp + ((c ^ sw) << 4));
-        const i32x4_t hi = *(const i32x4_t*)(rowp + (((c + 1) ^ sw) << 4));
+        const i32x4_t hi = *(const i32x4_t*)(rowp + (((c + 2) ^ sw) << 4));
         i32x8_t v;
         v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
         v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
         return v;
     };
-    auto compute = [&](int stage) {
+    // MX activation scales (AMX): per K-step one dword per activation row = the 4 block scales of its 128 k-bytes; a lane needs blocks
+    // (2*ks + lh), so the dword is pre-shifted by 8*lh and the instruction picks byte 0 (ks = 0) / byte 2 (ks = 1) through op_sel. The
+    // dword of K-step kt+1 is fetched while kt computes. Weights carry per-channel fp32 scales applied after the loop: unit block scales.
+    int unit_scale = 0x7f7f7f7f;
+    asm volatile("" : "+v"(unit_scale));  // opaque: a literal scale operand would be re-interpreted by the compiler as an fp32 constant
+    uint32_t mxoff[FY];
+    int ysc[FY];
+    if constexpr (AMX) {
+#pragma unroll
+        for (int fj = 0; fj < FY; ++fj) {
+            const int m = m0 + wm * MW + fj * 32 + l31;
+            mxoff[fj] = (uint32_t)(m < p.M ? m : p.M - 1) * (uint32_t)q.ld_mx;
+            ysc[fj] = (int)(*(const uint32_t*)(q.a_mx + mxoff[fj]) >> (8 * lh));
+        }
+    }
+    auto compute = [&](int stage, int ktn) {
         const char* sb = smem + stage * STAGE_BYTES;
+        int ynext[FY];
+        if constexpr (AMX) {
+#pragma unroll
+            for (int fj = 0; fj < FY; ++fj) ynext[fj] = (int)(*(const uint32_t*)(q.a_mx + mxoff[fj] + ktn * 4) >> (8 * lh));
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             i32x8_t xf[FX], yf[FY];
@@ -115,9 +159,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi)
 #pragma unroll
-                for (int fj = 0; fj < FY; ++fj)
-                    acc[fi][fj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0, 0, 0, 0);
+                for (int fj = 0; fj < FY; ++fj) {
+                    if constexpr (!AMX) acc[fi][fj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0, 0, 0, 0);
+                    else if (ks == 0) acc[fi][fj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0, unit_scale, 0, ysc[fj]);
+                    else acc[fi][fj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0, unit_scale, 2, ysc[fj]);
+                }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (AMX) {
+#pragma unroll
+            for (int fj = 0; fj < FY; ++fj) ysc[fj] = ynext[fj];
         }
     };
 
@@ -127,7 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
         if (kt + 1 < nk) dma_tile(kt + 1, stage ^ 1);
-        compute(stage);
+        compute(stage, kt + 1 < nk ? kt + 1 : kt);
         __syncthreads();
     }
 
@@ -135,7 +186,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
 #pragma unroll
     for (int fj = 0; fj < FY; ++fj) {
         const int m = m0 + wm * MW + fj * 32 + l31;
-        const float sa = q.a_scale[m < p.M ? m : p.M - 1];
+        const float sa = AMX ? 1.f : q.a_scale[m < p.M ? m : p.M - 1];  // MX activations were scaled inside the MFMA
 #pragma unroll
         for (int fi = 0; fi < FX; ++fi)
 #pragma unroll
@@ -147,31 +198,78 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
                 acc[fi][fj][4 * g + 3] *= sa * s4.w;
             }
     }
-    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh);
+    if constexpr (EPI == EPI_GEGLU && (FX % 2) == 0) {
+        if (q.mx_out != nullptr) {
+            // GEGLU with MX fp8 output: value*gelu(gate) as in the shared epilogue, then every 32 output columns of a row (= two
+            // fragments x {this lane, lane^32}) get their own power-of-two scale 2^e >= max|h| / 448 and leave as e4m3 bytes: the
+            // FeedForward's second GEMM consumes them through a_mx with no quantisation pass in between.
+            const float* __restrict__ bias = p.bias;
+            const int nout = p.N >> 1;
+#pragma unroll
+            for (int fj = 0; fj < FY; ++fj) {
+                const int m = m0 + wm * MW + fj * 32 + l31;
+                if (m >= p.M) continue;  // both lanes of a row leave together
+#pragma unroll
+                for (int fp = 0; fp < FX; fp += 2) {
+                    float h[2][2][4];
+                    float amax = 0.f;
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const int nfrag = n0 + wn * NW + (fp + f) * 32;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const int np = nfrag + 8 * g + 4 * lh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float a = acc[fp + f][fj][4 * g + e], gt = acc[fp + f][fj][4 * (g + 2) + e];
+                                if (bias) { a += bias[np + e]; gt += bias[np + 16 + e]; }
+                                const float v = a * gelu_erf_f(gt);
+                                h[f][g][e] = v;
+                                amax = fmaxf(amax, fabsf(v));
+                            }
+                        }
+                    }
+                    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                    int ex = 0;
+                    if (amax > 0.f) frexpf(amax * (1.f / 448.f), &ex);  // amax/448 = f * 2^ex, f in [0.5, 1)  ->  2^ex >= amax/448
+                    else ex = -127;
+                    ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
+                    const float inv = ldexpf(1.f, -ex);
+                    uint32_t qd[2][2];
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g)
+                            qd[f][g] = pack_fp8x4(h[f][g][0] * inv, h[f][g][1] * inv, h[f][g][2] * inv, h[f][g][3] * inv);
+                    const uint4 w = widen_quads_fp8(qd[0][0], qd[0][1], qd[1][0], qd[1][1]);
+                    const int nc0 = (n0 + wn * NW + fp * 32) >> 1;  // first output column of the 32-column block
+                    if (nc0 + 16 * lh < nout) *(uint4*)((uint8_t*)p.out + (size_t)m * p.ldc + nc0 + 16 * lh) = w;
+                    if (lh == 0 && nc0 < nout) q.mx_out[(size_t)m * q.ld_mx_out + (nc0 >> 5)] = (uint8_t)(ex + 127);
+                }
+            }
+            return;
+        }
+    }
+    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn);
 }
 
-template <int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
+template <int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, int FN>
 int launch_cfg(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tiles = ((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, OUT_F32, WM, WN, FM, FN>), dim3(tiles), dim3(WM * WN * 64), 0, stream, *d, q);
+    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, OUT_F32, AMX, WM, WN, FM, FN>), dim3(tiles), dim3(WM * WN * 64), 0, stream, *d, q);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
 
-template <int EPI, bool OUT_F32>
+int fp8_cfg(const VkGemmDesc* d);
+
+template <int EPI, bool OUT_F32, bool AMX>
 int launch(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
-    int cfg = d->tile_cfg & 7;
-    if (cfg == 0) {
-        auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
-        const int n256 = (d->N + 255) / 256 * 256;
-        if (EPI != EPI_GEGLU && d->N % 320 == 0 && wgs(256, 320) >= 192) cfg = 4;  // GEGLU: 256x256 measured faster
-        else if (n256 * 10 <= d->N * 11 && wgs(256, 256) >= 192) cfg = 3;
-        else cfg = 1;
-    }
-    if (cfg == 4) return launch_cfg<EPI, OUT_F32, 4, 2, 2, 5>(d, q, stream);
-    if (cfg == 3) return launch_cfg<EPI, OUT_F32, 4, 4, 2, 2>(d, q, stream);  // sixteen 64x64 wave tiles, 4 waves per SIMD (as in gemm.hip)
-    return launch_cfg<EPI, OUT_F32, 2, 2, 2, 2>(d, q, stream);
+    const int cfg = fp8_cfg(d);
+    if (cfg == 4 && EPI != EPI_GEGLU) return launch_cfg<EPI, OUT_F32, AMX, 4, 2, 2, 5>(d, q, stream);
+    if (cfg >= 3) return launch_cfg<EPI, OUT_F32, AMX, 4, 4, 2, 2>(d, q, stream);  // sixteen 64x64 wave tiles, 4 waves per SIMD (as in gemm.hip)
+    return launch_cfg<EPI, OUT_F32, AMX, 2, 2, 2, 2>(d, q, stream);
 }
 
 // one wave per row: amax -> scale = amax / 448, q = e4m3(x / scale)
@@ -221,19 +319,53 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const uint16_t* __re
 
 }  // namespace
 
-extern "C" int vk_gemm_fp8(const VkGemmDesc* d, const float* a_scale, const float* w_scale, int32_t k_real, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!d || !d->A || !d->Wt || !d->out || !a_scale || !w_scale) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) != 0 || (d->N % 4) != 0 || k_real <= 0 || k_real > d->K || (k_real % 16) != 0 ||
-        d->lda < k_real || (d->lda % 16) != 0 || d->amode != AMODE_DENSE || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 7)
+namespace {
+int fp8_cfg(const VkGemmDesc* d) {  // the tile variant launch<>() picks (1 = 128x128, 3 = 256x256, 4 = 256x320)
+    int cfg = d->tile_cfg & 7;
+    if (cfg == 0) {
+        auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
+        const int n256 = (d->N + 255) / 256 * 256;
+        if (d->epi != EPI_GEGLU && d->N % 320 == 0 && wgs(256, 320) >= 192) cfg = 4;
+        else if (n256 * 10 <= d->N * 11 && wgs(256, 256) >= 192) cfg = 3;
+        else cfg = 1;
+    }
+    return (cfg == 4 || cfg == 3) ? cfg : 1;
+}
+
+int gemm_fp8_entry(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
+    if (!d || !d->A || !d->Wt || !d->out || (!q.a_scale && !q.a_mx) || (q.a_scale && q.a_mx) || !q.w_scale) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) != 0 || (d->N % 4) != 0 || q.K <= 0 || q.K > d->K || (q.K % 16) != 0 ||
+        d->lda < q.K || (d->lda % 16) != 0 || d->amode != AMODE_DENSE || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 7)
         return VK_EINVAL;
     if ((d->rowvec || d->rowvec2) && d->rows_per_vec <= 0) return VK_EINVAL;
-    if (d->ln_stats || d->rowstat_out || d->A2 || (d->rowvec2 && !d->res2)) return VK_EINVAL;  // bf16-GEMM-only features
-    const F8Args q{a_scale, w_scale, k_real};
+    if (d->ln_stats || d->A2 || (d->rowvec2 && !d->res2)) return VK_EINVAL;  // bf16-GEMM-only features
+    if (d->rowstat_out && (d->epi != EPI_LINEAR || d->out_f32)) return VK_EINVAL;
+    if (q.a_mx && (q.ld_mx * 32 < d->K || (q.ld_mx % 4) != 0 || (q.K % 32) != 0)) return VK_EINVAL;  // one dword of block scales per 128-byte K-step
+    if (q.mx_out && (d->epi != EPI_GEGLU || ((d->N >> 1) % 32) != 0 || (d->ldc % 16) != 0 || q.ld_mx_out * 32 < (d->N >> 1))) return VK_EINVAL;
     const bool f32 = d->out_f32 != 0;
-    if (d->epi == EPI_LINEAR) return f32 ? launch<EPI_LINEAR, true>(d, q, stream) : launch<EPI_LINEAR, false>(d, q, stream);
-    if (d->epi == EPI_GEGLU && !f32 && (d->N % 32) == 0) return launch<EPI_GEGLU, false>(d, q, stream);
+    if (q.a_mx) return (d->epi == EPI_LINEAR && !f32) ? launch<EPI_LINEAR, false, true>(d, q, stream) : VK_EINVAL;  // the FF-out GEMM
+    if (d->epi == EPI_LINEAR) return f32 ? launch<EPI_LINEAR, true, false>(d, q, stream) : launch<EPI_LINEAR, false, false>(d, q, stream);
+    if (d->epi == EPI_GEGLU && !f32 && (d->N % 32) == 0) return launch<EPI_GEGLU, false, false>(d, q, stream);
     return VK_EINVAL;
+}
+}  // namespace
+
+extern "C" int vk_gemm_fp8(const VkGemmDesc* d, const float* a_scale, const float* w_scale, int32_t k_real, void* stream_) {
+    const F8Args q{a_scale, w_scale, k_real, nullptr, 0, nullptr, 0};
+    return gemm_fp8_entry(d, q, (hipStream_t)stream_);
+}
+
+extern "C" int vk_gemm_fp8_mx(const VkGemmDesc* d, const VkFp8Args* a, void* stream_) {
+    if (!a) return VK_EINVAL;
+    const F8Args q{a->a_scale, a->w_scale, a->k_real, (const uint8_t*)a->a_mx, a->ld_mx, (uint8_t*)a->mx_out, a->ld_mx_out};
+    return gemm_fp8_entry(d, q, (hipStream_t)stream_);
+}
+
+extern "C" int vk_gemm_fp8_rowstat_parts(const VkGemmDesc* d) {
+    if (!d || d->epi != EPI_LINEAR || d->out_f32 || d->N <= 0) return VK_EINVAL;
+    const int cfg = fp8_cfg(d);
+    const int bn = cfg == 4 ? 320 : (cfg == 3 ? 256 : 128), wn = cfg == 4 ? 2 : (cfg == 3 ? 4 : 2);
+    return ((d->N + bn - 1) / bn) * wn;
 }
 
 extern "C" int vk_quantize_rows_fp8(const void* x, void* q, float* scale, int32_t M, int32_t K, int64_t ldx, int64_t ldq, void* stream_) {

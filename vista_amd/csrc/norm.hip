@@ -242,6 +242,75 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restri
     }
 }
 
+// LayerNorm fused with per-row fp8 (e4m3) quantisation: one wave per row, the normalised row stays in registers: mean / centred variance,
+// y = (x - mean) * rstd * gamma + beta, scale = max|y| / 448, q = e4m3(y / scale). The bf16 normalised tensor is never written.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_quant_kernel(const uint16_t* __restrict__ x, uint8_t* __restrict__ qo, float* __restrict__ scale,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int rows, int C,
+                                                              float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int CG = C >> 3;
+    const int nw = gridDim.x * 4;
+    const float inv_c = 1.f / (float)C;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += nw) {
+        float f[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < CG) {
+                unpack8(*(const uint4*)(x + (size_t)row * C + ch * 8), f[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[j][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[j][e] = 0.f;
+            }
+        }
+        const float mean = wave_sum(s) * inv_c;
+        float qv = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+            if (lane + 64 * j < CG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[j][e] - mean; qv += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(qv) * inv_c + eps);
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < CG) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f[j][e] = fmaf((f[j][e] - mean) * rstd, gamma[ch * 8 + e], beta[ch * 8 + e]);
+                    amax = fmaxf(amax, fabsf(f[j][e]));
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        const float sc = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+        const float inv = 1.f / sc;
+        if (lane == 0) scale[row] = sc;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int ch = lane + 64 * j;
+            if (ch < CG) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fminf(fmaxf(f[j][e] * inv, -448.f), 448.f);  // the cvt yields NaN above 448, it does not saturate
+                int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+                int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+                hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+                *(int2*)(qo + (size_t)row * C + ch * 8) = make_int2(lo, hi);
+            }
+        }
+    }
+}
+
 // Row sums for a LayerNorm folded into the consumer GEMM: one wave per row, stats[row] = (sum x, sum x^2), lane partials over the
 // row's 16-B chunks then a fixed butterfly -- bitwise reproducible.
 __global__ __launch_bounds__(256) void rowstats_kernel(const uint16_t* __restrict__ x, float2* __restrict__ stats, int rows, int C, long long ldx) {
@@ -385,6 +454,24 @@ extern "C" int vk_layernorm_bf16(const void* x, void* y, void* sum_out, const fl
     else if (nch == 2) LN_LAUNCH(2);
     else LN_LAUNCH(3);
 #undef LN_LAUNCH
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
+extern "C" int vk_layernorm_quant_fp8(const void* x, void* q, float* scale, const float* gamma, const float* beta, int32_t rows, int32_t C,
+                                      float eps, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !q || !scale || !gamma || !beta || rows <= 0 || C <= 0 || (C % 8) != 0 || C > 1536) return VK_EINVAL;
+    const int nch = (C / 8 + 63) / 64;
+    long long want = ((long long)rows + 3) / 4;
+    const long long cap = 256LL * 8;
+    const int grid = (int)(want < cap ? want : cap);
+#define LNQ_LAUNCH(N)                                                                                                                     \
+    hipLaunchKernelGGL(layernorm_quant_kernel<N>, dim3(grid), dim3(256), 0, stream, (const uint16_t*)x, (uint8_t*)q, scale, gamma, beta, rows, C, eps)
+    if (nch == 1) LNQ_LAUNCH(1);
+    else if (nch == 2) LNQ_LAUNCH(2);
+    else LNQ_LAUNCH(3);
+#undef LNQ_LAUNCH
     VK_CHECK_LAUNCH();
     return VK_OK;
 }

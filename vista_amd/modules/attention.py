@@ -126,10 +126,17 @@ class FeedForward(nn.Module, Packable):
     def forward_folded(self, x, stats, pw_in, norm, **epilogue):
         """net(LayerNorm(x)) with the LayerNorm folded into the GEGLU GEMM: x (M, dim) is the un-normalised residual stream,
         `stats` its RowStats, `pw_in` = pack_in_folded(norm). No normalised tensor is ever written (attention.py:524)."""
-        if FP8["feedforward"]:  # config-5 experiment keeps the explicit LayerNorm (it quantises the normalised rows)
-            emit = epilogue.pop("emit_stats", False)
-            out = self.forward(ops.layernorm(x, norm.weight, norm.bias, norm.eps), **epilogue)
-            return (out, ops.rowstats(out)) if emit else out
+        if FP8["feedforward"]:
+            # BASELINE config 5: both GEMMs in fp8 e4m3 with NO stand-alone quantisation pass. LayerNorm + per-row quantisation is one
+            # kernel (the normalised rows exist only as fp8), the GEGLU epilogue quantises its own output to MX fp8 (a power-of-two scale
+            # per 32 columns), and the out-projection applies those block scales inside v_mfma_scale_f32_32x32x64_f8f6f4.
+            pk = self.packed()
+            if "in8" not in pk:  # the switch was flipped after the bf16 pack was built
+                self.invalidate_packed()
+                pk = self.packed()
+            yq, ys = ops.layernorm_quant_fp8(x, norm)
+            h8, hs = ops.linear_fp8(yq, ys, pk["in8"], mx_out=True)
+            return ops.linear_fp8(h8, None, pk["out8"], a_mx=hs, **epilogue)
         return ops.linear(ops.linear(x, pw_in, ln=stats), self.packed()["out"], **epilogue)
 
 

@@ -11,7 +11,7 @@ import threading
 import torch
 
 from . import _lib
-from ._lib import VkGemmDesc, check
+from ._lib import VkFp8Args, VkGemmDesc, check
 
 AMODE_DENSE, AMODE_CONV3X3, AMODE_TEMPORAL3, AMODE_CONV3D = 0, 1, 2, 3
 EPI_LINEAR, EPI_GEGLU, EPI_TRANS = 0, 1, 2
@@ -446,16 +446,41 @@ def quantize_rows_fp8(x):
     return q, scale
 
 
+def layernorm_quant_fp8(x, norm):
+    """LayerNorm fused with per-row e4m3 quantisation (one pass): x (..., C) bf16 -> (q uint8 (M, C), scale f32 (M,)) with LN(x) ~= q * scale[:, None]."""
+    _need(x, BF16, "x")
+    if not x.is_contiguous():
+        raise ValueError("layernorm_quant_fp8: x must be contiguous")
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    q = torch.empty((M, Cc), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((M,), dtype=F32, device=x.device)
+    check(_lib.load().vk_layernorm_quant_fp8(_p(x), _p(q), _p(scale), _p(norm.weight), _p(norm.bias), M, Cc, float(norm.eps), _stream()),
+          "vk_layernorm_quant_fp8")
+    return q, scale
+
+
 def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0,
-               rowvec2=None):
-    """out = alpha*((xq*a_scale) @ (Wq*w_scale)^T + bias + rowvec + res1) + beta*res2, fp8 x fp8 -> f32 accumulate."""
+               rowvec2=None, a_mx=None, mx_out=False, emit_stats=False):
+    """out = alpha*((xq*scales) @ (Wq*w_scale)^T + bias + rowvec + res1) + beta*(res2 + rowvec2), fp8 x fp8 -> f32 accumulate.
+    Activation scales: `a_scale` f32 (M,) per row, OR `a_mx` uint8 (M, K/32) E8M0 block scales (MX; a_scale None).
+    mx_out (GEGLU weights only): return (h8 uint8 (M, nout), hs uint8 (M, nout/32)) -- the gated output quantised to MX fp8 in the epilogue.
+    emit_stats: also return the RowStats of the (bf16) output."""
     if xq.dtype != torch.uint8 or xq.dim() != 2 or xq.stride(1) != 1:
         raise TypeError("linear_fp8: xq must be a (M, K) uint8 tensor of e4m3 bytes")
     M, K = xq.shape
     if K != pw.K:
         raise ValueError(f"linear_fp8: K mismatch {K} vs {pw.K}")
+    if (a_scale is None) == (a_mx is None):
+        raise ValueError("linear_fp8: exactly one of a_scale (per row) / a_mx (MX block scales)")
     nout = pw.N // 2 if pw.geglu else pw.N
-    if out is None:
+    hs = None
+    if mx_out:
+        if not pw.geglu or nout % 32:
+            raise ValueError("mx_out: GEGLU weights with an output width that is a multiple of 32")
+        out = torch.empty((M, nout), dtype=torch.uint8, device=xq.device)
+        hs = torch.empty((M, nout // 32), dtype=torch.uint8, device=xq.device)
+    elif out is None:
         out = torch.empty((M, nout), dtype=F32 if (out_f32 and not pw.geglu) else BF16, device=xq.device)
     d = VkGemmDesc()
     d.A, d.lda = _p(xq), xq.stride(0)
@@ -464,8 +489,26 @@ def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_pe
     _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta, rowvec2)
     d.K = pw.Kp
     d.tile_cfg = TILE_CFG & 7
-    check(_lib.load().vk_gemm_fp8(C.byref(d), _p(a_scale), _p(pw.scale), K, _stream()), "vk_gemm_fp8")
-    return out
+    lib = _lib.load()
+    stats = None
+    if emit_stats:
+        parts = lib.vk_gemm_fp8_rowstat_parts(C.byref(d))
+        if parts <= 0:
+            raise _lib.VistaHipError(f"vk_gemm_fp8_rowstat_parts failed with code {parts}")
+        stats = RowStats(torch.empty((parts, M, 2), dtype=F32, device=xq.device), parts, M)
+        d.rowstat_out = _p(stats.t)
+    a = VkFp8Args()
+    a.a_scale, a.w_scale, a.k_real = _p(a_scale), _p(pw.scale), K
+    if a_mx is not None:
+        if a_mx.dtype != torch.uint8 or a_mx.shape != (M, K // 32) or not a_mx.is_contiguous():
+            raise ValueError("a_mx: contiguous uint8 (M, K/32) E8M0 block scales")
+        a.a_mx, a.ld_mx = _p(a_mx), a_mx.stride(0)
+    if mx_out:
+        a.mx_out, a.ld_mx_out = _p(hs), hs.stride(0)
+    check(lib.vk_gemm_fp8_mx(C.byref(d), C.byref(a), _stream()), "vk_gemm_fp8_mx")
+    if mx_out:
+        return out, hs
+    return (out, stats) if emit_stats else out
 
 
 # ---------------------------------------------------------------------------------------------- attention
