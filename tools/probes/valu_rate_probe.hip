@@ -58,6 +58,8 @@ __global__ __launch_bounds__(1024) void probe(float* out, int iters) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc1, 0, 0, 0);
             }
+        } else if (OP == 13) {  // ONE dependent MFMA chain (8 per iteration)
+            for (int j = 0; j < 8; ++j) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc0, 0, 0, 0);
         } else if (OP == 8) {  // exp and fma interleaved in ONE wave: serial (sum) or co-executed (max)?
 #define S(i) asm volatile("v_exp_f32 %0, %0\n\tv_fma_f32 %1, %1, %2, %2" : "+v"(a[i]), "+v"(c2[i][0]) : "v"(b[i]));
             REP8(S)
@@ -95,17 +97,17 @@ typedef void (*kern_t)(float*, int);
 int main() {
     float* out;
     hipMalloc(&out, 4096);
-    const char* names[] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "v_dot2c_f32_bf16", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_pk_add_f32",
+    const char* names[14] = {"v_fma_f32", "v_exp_f32", "v_pk_fma_f32", "v_dot2c_f32_bf16", "v_cvt_pk_bf16_f32", "v_max3_f32", "v_pk_add_f32",
                            "v_mfma_f32_32x32x16_bf16", "exp+fma pairs (per pair)", "8 mfma + 8 exp + 8 fma (per group of 3)", "v_add_f32",
-                           "v_exp_f16", "v_mul+v_ldexp (per pair)"};
-    kern_t ks[] = {probe<0>, probe<1>, probe<2>, probe<3>, probe<4>, probe<5>, probe<6>, probe<7>, probe<8>, probe<9>, probe<10>, probe<11>, probe<12>};
+                           "v_exp_f16", "v_mul+v_ldexp (per pair)", "v_mfma one dependent chain"};
+    kern_t ks[] = {probe<0>, probe<1>, probe<2>, probe<3>, probe<4>, probe<5>, probe<6>, probe<7>, probe<8>, probe<9>, probe<10>, probe<11>, probe<12>, probe<13>};
     const int iters = 20000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     double fma_ns[5] = {0};
     for (int wps = 1; wps <= 4; wps *= 2) {  // waves per SIMD
-        for (int k = 0; k < 13; ++k) {
+        for (int k = 0; k < 14; ++k) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(e0, 0);

@@ -1,5 +1,7 @@
-"""Summarise a rocprofv3 results DB (rocpd sqlite) into a per-kernel table (the `--stats` view) as text.
-Usage: python tools/prof_summary.py <results.db> [header text] > profiles/xxx.txt"""
+"""Summarise a rocprofv3 --kernel-trace result into a per-kernel table (the `--stats` view) as text.
+Usage: python tools/prof_summary.py <results.db | out_kernel_trace.csv> [header text] > profiles/xxx.txt
+(rocpd sqlite DB of the default output format, or the kernel-trace CSV of `--output-format csv`)"""
+import csv
 import re
 import sqlite3
 import sys
@@ -21,7 +23,39 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
+def from_csv(path):
+    """The same three tables from out_kernel_trace.csv (one row per dispatch, timestamps in ns)."""
+    agg, attn, gemm = {}, {}, {}
+    total = 0.0
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            n = r["Kernel_Name"]
+            d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            total += d
+            e = agg.setdefault(short(n), [0, 0.0])
+            e[0] += 1; e[1] += d
+            gx, wx = int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"])
+            for tab, key in ((attn, "attn_spatial_kernel"), (gemm, "gemm_kernel")):
+                if key in n:
+                    g = tab.setdefault((short(n) if key == "gemm_kernel" else re.search(r"attn_spatial_kernel<[^>]*>", n).group(0), gx, wx), [0, 0.0])
+                    g[0] += 1; g[1] += d
+    if len(sys.argv) > 2:
+        print(sys.argv[2])
+    print(f"{'kernel':62s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"{k:62s} {c:7d} {t/1e6:10.2f} {t/c/1e3:10.2f} {100*t/total:6.2f}")
+    print(f"{'TOTAL':62s} {sum(v[0] for v in agg.values()):7d} {total/1e6:10.2f}")
+    print("\nattn_spatial_kernel by launch geometry (grid_x = threads):")
+    for (n, gx, wx), (c, t) in sorted(attn.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {n:28s} grid_x {gx:9d} wg {wx:4d}  calls {c:4d}  avg_us {t/c/1e3:9.2f}  total_ms {t/1e6:8.2f}")
+    print("\ngemm_kernel by launch geometry (grid_x = threads = workgroups x workgroup size), top 28 by total time:")
+    for (n, gx, wx), (c, t) in sorted(gemm.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"  {n:44s} wgs {gx // wx:6d} x {wx:4d}  calls {c:4d}  avg_us {t/c/1e3:9.2f}  total_ms {t/1e6:8.2f}")
+
+
 def main():
+    if sys.argv[1].endswith(".csv"):
+        return from_csv(sys.argv[1])
     db = sqlite3.connect(sys.argv[1])
     rows = list(db.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
     agg = {}

@@ -69,13 +69,16 @@ __device__ __forceinline__ float dot2_ones(uint32_t packed, float acc) {  // acc
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v_t, packed), one, acc, false);
 }
 
-template <int NW>  // waves per workgroup: NW*32 query rows share each 64-key K / V^T tile
-__global__ __launch_bounds__(NW * 64, 4) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
-                                                                  const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
-                                                                  int n_img, int heads, int S, int ldq, int ldk, int ldo,
-                                                                  float scale_log2, float rescale_thr) {
-    constexpr int QB = NW * 32;   // query rows per workgroup
-    constexpr int GPW = 8 / NW;   // 8-row DMA groups of each tile handled per wave
+// NW waves per workgroup, QW 32-row query blocks per wave: NW*QW*32 query rows share each 64-key K / V^T tile. QW = 2 (long sequences)
+// feeds every K / V^T fragment read to TWO MFMAs: the K-loop of these kernels is LDS-throughput-bound (profiles/r02_ab_notes.txt A/B 2),
+// and the price -- twice the accumulators, 2 waves per SIMD instead of 4 -- is paid in latency hiding the loop does not depend on.
+template <int NW, int QW>
+__global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                                                const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
+                                                                                int n_img, int heads, int S, int ldq, int ldk, int ldo,
+                                                                                float scale_log2, float rescale_thr) {
+    constexpr int QB = NW * QW * 32;  // query rows per workgroup
+    constexpr int GPW = 8 / NW;       // 8-row DMA groups of each tile handled per wave
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // per stage: K tile 8 KiB | V^T tile 8 KiB
 
     const int tid = threadIdx.x;
@@ -89,14 +92,18 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_kernel(const uint16_t
     const int img = bh / heads, head = bh - img * heads;
 
     // ---- Q fragments (B operand: column = query row, 8 consecutive d at 16*ks + 8*lh) ----
-    const int q0 = qb * QB + wave * 32;
-    int qrow = q0 + l31;
-    const bool q_ok = qrow < S;
-    if (!q_ok) qrow = S - 1;
-    const uint16_t* qptr = q + ((size_t)img * S + qrow) * ldq + head * 64 + 8 * lh;
-    bf16x8_t qf[4];
+    int qrow[QW];
+    bool q_ok[QW];
+    bf16x8_t qf[QW][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qptr + 16 * ks);
+    for (int b = 0; b < QW; ++b) {
+        qrow[b] = qb * QB + (wave * QW + b) * 32 + l31;
+        q_ok[b] = qrow[b] < S;
+        if (!q_ok[b]) qrow[b] = S - 1;
+        const uint16_t* qptr = q + ((size_t)img * S + qrow[b]) * ldq + head * 64 + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const bf16x8_t*)(qptr + 16 * ks);
+    }
 
     // ---- K / V^T staging by LDS-DMA: wave w fills the 8-row groups w, w+NW, .. of both tiles; lane -> row (lane>>3) of the
     //      group, physical 16-B slot (lane&7); the swizzle (slot = chunk ^ ((row>>1)&7)) is applied on the SOURCE chunk ----
@@ -135,12 +142,17 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_kernel(const uint16_t
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) frag_off[ks] = l31 * 128 + (((ks * 2 + lh) ^ fsw) << 4);
 
-    f32x16_t oacc[2];
+    f32x16_t oacc[QW][2];
+    float m_run[QW], l_run[QW];
 #pragma unroll
-    for (int d = 0; d < 2; ++d)
+    for (int b = 0; b < QW; ++b) {
+        m_run[b] = NEG_BIG;
+        l_run[b] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[b][d][r] = 0.f;
+    }
 
     const int nt = (S + 63) >> 6;
     const float psum_limit = fast_exp2(rescale_thr + 5.f);
@@ -153,19 +165,22 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_kernel(const uint16_t
         const char* sK = smem + stage * 16384;
         const char* sV = sK + 8192;
 
-        f32x16_t sacc[2];
-        bf16x8_t pf[4];
-        float psum;
-        // ---- S^T[key][q] = K . Q^T ----
+        f32x16_t sacc[QW][2];
+        bf16x8_t pf[QW][4];
+        float psum[QW];
+        // ---- S^T[key][q] = K . Q^T : every K fragment feeds the QW query blocks of the wave ----
         auto scores = [&]() {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[c][r] = 0.f;
+                for (int b = 0; b < QW; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[b][c][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + c * 32 * 128 + frag_off[ks]);
-                    sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[c], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QW; ++b) sacc[b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ks], sacc[b][c], 0, 0, 0);
                 }
             }
             if (t == nt - 1 && (S & 63)) {  // mask keys past the end of the sequence (last tile only)
@@ -175,7 +190,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_kernel(const uint16_t
                     for (int r = 0; r < 16; ++r) {
                         // accumulator row rho32 = (r&3) + 8*(r>>2) + 4*lh holds key key_of_row(rho32) of subtile c
                         const int key = t * 64 + c * 32 + key_of_row((r & 3) + 8 * (r >> 2) + 4 * lh);
-                        if (key >= S) sacc[c][r] = NEG_BIG;
+                        if (key >= S) {
+#pragma unroll
+                            for (int b = 0; b < QW; ++b) sacc[b][c][r] = NEG_BIG;
+                        }
                     }
             }
         };
@@ -184,44 +202,50 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_kernel(const uint16_t
         //      probabilities, two per v_dot2c_f32_bf16 (half the adds, and l matches what the PV MFMAs accumulate) ----
         auto probabilities = [&]() {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int b = 0; b < QW; ++b) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[c][r] = fast_exp2(fmaf(sacc[c][r], scale_log2, -m_run));
-            psum = 0.f;
+                for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int J = 0; J < 4; ++J) {
-                const int c = J >> 1, r0 = 8 * (J & 1);
-                uint4 v;
-                v.x = pack_bf16(sacc[c][r0 + 0], sacc[c][r0 + 1]);
-                v.y = pack_bf16(sacc[c][r0 + 2], sacc[c][r0 + 3]);
-                v.z = pack_bf16(sacc[c][r0 + 4], sacc[c][r0 + 5]);
-                v.w = pack_bf16(sacc[c][r0 + 6], sacc[c][r0 + 7]);
-                psum = dot2_ones(v.x, psum);
-                psum = dot2_ones(v.y, psum);
-                psum = dot2_ones(v.z, psum);
-                psum = dot2_ones(v.w, psum);
-                pf[J] = __builtin_bit_cast(bf16x8_t, v);
+                    for (int r = 0; r < 16; ++r) sacc[b][c][r] = fast_exp2(fmaf(sacc[b][c][r], scale_log2, -m_run[b]));
+                psum[b] = 0.f;
+#pragma unroll
+                for (int J = 0; J < 4; ++J) {
+                    const int c = J >> 1, r0 = 8 * (J & 1);
+                    uint4 v;
+                    v.x = pack_bf16(sacc[b][c][r0 + 0], sacc[b][c][r0 + 1]);
+                    v.y = pack_bf16(sacc[b][c][r0 + 2], sacc[b][c][r0 + 3]);
+                    v.z = pack_bf16(sacc[b][c][r0 + 4], sacc[b][c][r0 + 5]);
+                    v.w = pack_bf16(sacc[b][c][r0 + 6], sacc[b][c][r0 + 7]);
+                    psum[b] = dot2_ones(v.x, psum[b]);
+                    psum[b] = dot2_ones(v.y, psum[b]);
+                    psum[b] = dot2_ones(v.z, psum[b]);
+                    psum[b] = dot2_ones(v.w, psum[b]);
+                    pf[b][J] = __builtin_bit_cast(bf16x8_t, v);
+                }
             }
         };
         // ---- re-base of the online softmax on this tile's row maxima: m_run <- max(m_run, max_keys s), O and l scaled to the new base ----
         auto rebase = [&]() {
-            float mx = sacc[0][0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[0][r]);
+            for (int b = 0; b < QW; ++b) {
+                float mx = sacc[b][0][0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[1][r]);
-            mx = fmaxf(pair_max(mx) * scale_log2, NEG_BIG);
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = fast_exp2(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[b][0][r]);
 #pragma unroll
-            for (int d = 0; d < 2; ++d)
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][1][r]);
+                mx = fmaxf(pair_max(mx) * scale_log2, NEG_BIG);
+                const float m_new = fmaxf(m_run[b], mx);
+                const float alpha = fast_exp2(m_run[b] - m_new);
+                m_run[b] = m_new;
+                l_run[b] *= alpha;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[b][d][r] *= alpha;
+            }
         };
 
-        // MAX-FREE FAST PATH. The loop is bound by the SUM of its VALU and MFMA issue time (profiles/r02_attn_ablation.txt), and the
+        // MAX-FREE FAST PATH. The loop costs close to the SUM of its VALU and MFMA issue time (profiles/r02_attn_ablation.txt), and the
         // row-maximum tree is ~30 of its ~150 VALU instructions per tile -- for a result that changes nothing on almost every tile:
         // after the first tiles a row's maximum hardly ever grows by more than a few octaves. So the exponentials are taken against
         // the EXISTING base without looking at the maximum, and the tile is validated AFTERWARDS through the row sum it needs anyway:
@@ -233,39 +257,48 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_spatial_kernel(const uint16_t
         scores();
         if (__builtin_expect(t == 0, 0)) rebase();
         probabilities();
-        if (__builtin_expect(__any(!(psum <= psum_limit)), 0)) {  // wave-uniform, rare
+        bool bad = !(psum[0] <= psum_limit);
+#pragma unroll
+        for (int b = 1; b < QW; ++b) bad = bad || !(psum[b] <= psum_limit);
+        if (__builtin_expect(__any(bad), 0)) {  // wave-uniform, rare
             asm volatile("" ::: "memory");  // re-read the fragments: keeping the fast path's copies alive for this branch costs spills
             scores();
             rebase();
             probabilities();
         }
-        l_run += psum;
+#pragma unroll
+        for (int b = 0; b < QW; ++b) l_run[b] += psum[b];
 
-        // ---- O^T[d][q] += V^T . P^T : V^T fragment (row d = 32*dd + l31, keys 16J + 8*lh ..+7) is one ds_read_b128 ----
+        // ---- O^T[d][q] += V^T . P^T : V^T fragment (row d = 32*dd + l31, keys 16J + 8*lh ..+7) is one ds_read_b128, shared by the
+        //      wave's query blocks ----
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
 #pragma unroll
             for (int J = 0; J < 4; ++J) {
                 const bf16x8_t vf = *(const bf16x8_t*)(sV + d * 32 * 128 + frag_off[J]);
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[J], oacc[d], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < QW; ++b) oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][J], oacc[b][d], 0, 0, 0);
             }
         }
         __syncthreads();  // retires the DMA of tile t+1 (vmcnt(0)) and frees this stage
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
-    if (q_ok) {
-        uint16_t* optr = o + ((size_t)img * S + qrow) * ldo + head * 64 + 4 * lh;
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+    for (int b = 0; b < QW; ++b) {
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        const float inv = 1.f / l_tot;
+        if (q_ok[b]) {
+            uint16_t* optr = o + ((size_t)img * S + qrow[b]) * ldo + head * 64 + 4 * lh;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack_bf16(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
-                w.y = pack_bf16(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
-                *(uint2*)(optr + 32 * d + 8 * g) = w;
-            }
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = pack_bf16(oacc[b][d][4 * g + 0] * inv, oacc[b][d][4 * g + 1] * inv);
+                    w.y = pack_bf16(oacc[b][d][4 * g + 2] * inv, oacc[b][d][4 * g + 3] * inv);
+                    *(uint2*)(optr + 32 * d + 8 * g) = w;
+                }
+        }
     }
 }
 
@@ -465,17 +498,21 @@ extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt
     // long sequences: 256 query rows (8 waves) per workgroup halve the K/V^T stream per FLOP; short ones keep 128 rows so the
     // ragged last q-block wastes less (S = 144, 576 at the deep levels)
     static const float thr = [] { const char* e = getenv("VISTA_ATTN_RESCALE_THR"); return e ? (float)atof(e) : RESCALE_THR; }();  // tuning / A-B
-    const bool big = S >= 2048;
-    const int qb_rows = big ? 256 : 128;
+    // long sequences: 8 waves x 64 query rows (512 per workgroup): every K / V^T fragment read feeds two MFMAs and the K/V^T stream
+    // per FLOP halves again; medium ones 8 x 32; short ones 4 x 32 so the ragged last q-block wastes less (S = 144, 576 at the deep levels)
+    static const int qw_env = [] { const char* e = getenv("VISTA_ATTN_QW"); return e ? atoi(e) : 0; }();  // tuning / A-B: 1 or 2
+    const int cls = S >= 4096 ? (qw_env == 1 ? 1 : 2) : (S >= 2048 ? 1 : 0);
+    const int qb_rows = cls == 2 ? 512 : (cls == 1 ? 256 : 128);
     const int nqb = (S + qb_rows - 1) / qb_rows;
     const long long nblk = (long long)nqb * n_img * heads;
     if (nblk > 0x7fffffffLL) return VK_EINVAL;
-    if (big)
-        hipLaunchKernelGGL(attn_spatial_kernel<8>, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream_, (const uint16_t*)q,
-                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr);
-    else
-        hipLaunchKernelGGL(attn_spatial_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)q,
-                           (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr);
+#define ATTN_LAUNCH(NW, QW)                                                                                                                 \
+    hipLaunchKernelGGL((attn_spatial_kernel<NW, QW>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint16_t*)q,       \
+                       (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr)
+    if (cls == 2) ATTN_LAUNCH(8, 2);
+    else if (cls == 1) ATTN_LAUNCH(8, 1);
+    else ATTN_LAUNCH(4, 1);
+#undef ATTN_LAUNCH
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
