@@ -119,12 +119,32 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
     const uint16_t* kbase = k + (size_t)img * S * ldk + head * 64;
     const uint16_t* vbase = vt + ((size_t)(img * heads + head) * 64) * S;
 
+    // Per-lane byte offsets inside a tile are loop-invariant; the tile itself moves the UNIFORM base (scalar adds), so a full tile costs
+    // no per-lane address arithmetic. Only a ragged LAST tile needs the per-key bounds test (its missing keys read the zero word).
+    uint32_t k_off[GPW], v_off[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        k_off[i] = (uint32_t)(k_key[i] * ldk + src_chunk[i] * 8) * 2u;
+        v_off[i] = (uint32_t)(d_row[i] * S + src_chunk[i] * 8) * 2u;
+    }
+    const bool ragged = (S & 63) != 0;
+    const int n_tiles = (S + 63) >> 6;
     auto dma_tile = [&](int t, int stage) {
         typedef const __attribute__((address_space(1))) void* gptr_t;
         typedef __attribute__((address_space(3))) void* lptr_t;
         const int key0 = t * 64;
         char* sK = smem + stage * 16384 + wave_u * 1024;
         char* sV = sK + 8192;
+        if (NW == 8 && !(ragged && t == n_tiles - 1)) {  // (the 4-wave kernel of the short sequences has no registers to spare for it)
+            const char* kt = (const char*)kbase + (size_t)key0 * ldk * 2;  // uniform
+            const char* vtile = (const char*)vbase + (size_t)key0 * 2;
+#pragma unroll
+            for (int i = 0; i < GPW; ++i) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(kt + k_off[i]), (lptr_t)(sK + i * NW * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(vtile + v_off[i]), (lptr_t)(sV + i * NW * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < GPW; ++i) {
             const int key = key0 + k_key[i];
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
             for (int r = 0; r < 16; ++r) oacc[b][d][r] = 0.f;
     }
 
-    const int nt = (S + 63) >> 6;
+    const int nt = n_tiles;
     const float psum_limit = fast_exp2(rescale_thr + 5.f);
     dma_tile(0, 0);
     __syncthreads();
