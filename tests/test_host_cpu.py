@@ -237,3 +237,24 @@ def test_video_unet_survives_deepcopy_and_pickle():
     again = pickle.loads(pickle.dumps(net))
     assert all(m._emb_src[0] is again._emb_tls for m in again._emb_blocks)
     assert [k for k in again.state_dict()] == [k for k in net.state_dict()]
+
+
+def test_gelu_logistic_quintic_formula():
+    """csrc/common.h gelu_erf_f: x * Phi(x) with Phi as a logistic of an odd quintic. The same fp32 arithmetic here against the erf
+    form (F.gelu, the reference's GEGLU, attention.py:92): |error| <= 2.6e-5 for every x, no NaN / inf at the extremes, and the
+    constants in the header are the ones evaluated."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "vista_amd", "csrc", "common.h")).read()
+    body = src[src.index("float gelu_erf_f(float x)"):]
+    c2, c1, c0 = (float(v) for v in re.search(r"fmaf\(u, fmaf\(u, ([-0-9.e]+)f, ([-0-9.e]+)f\), ([-0-9.e]+)f\)", body).groups())
+    clamp = float(re.search(r"fminf\(x \* x, ([0-9.]+)f\)", body).group(1))
+    x = torch.cat([torch.linspace(-30, 30, 1_000_001), torch.tensor([-1e4, 1e4, -3e38, 3e38, 0.0])]).float()
+    u = torch.minimum(x * x, torch.tensor(clamp))
+    t = torch.addcmul(torch.tensor(c0), u, torch.addcmul(torch.tensor(c1), u, torch.tensor(c2)))
+    got = x * (1.0 / (1.0 + torch.exp2(x * t)))
+    ref = torch.nn.functional.gelu(x.double()).float()
+    assert torch.isfinite(got).all()
+    fin = x.abs() <= 1e4
+    assert (got[fin] - ref[fin]).abs().max().item() <= 2.6e-5
+    assert got[-2].item() == ref[-2].item() and got[-3].item() == 0.0   # +3e38 -> x, -3e38 -> -0
