@@ -84,7 +84,10 @@ int vk_gemm_fp8(const VkGemmDesc* desc, const float* a_scale, const float* w_sca
  *   mx_out / ld_mx_out: EPI_GEGLU only: write the gated output as MX fp8 -- d->out = e4m3 bytes [M][d->ldc], mx_out = E8M0 [M][ld_mx_out],
  *                      one scale per 32 output columns, chosen in the epilogue (2^e >= max|h| / 448) -- so that the FeedForward's second
  *                      GEMM (a_mx = this mx_out) needs no quantisation pass (attention.py:85-128). (N/2) % 32 == 0, ldc % 16 == 0.
- * d->rowstat_out is honoured (vk_gemm_fp8_rowstat_parts sizes it). */
+ * d->rowstat_out is honoured (vk_gemm_fp8_rowstat_parts sizes it).
+ * Implicit-GEMM convolutions (d->amode = CONV3X3 / TEMPORAL3, the ResBlock convolutions of openaimodel.py:300-318 / video_model.py:38-52 on
+ * the e4m3 output of vk_groupnorm_silu_fp8): stride 1, pad 1, no upsample / halo, weights [Cout][Cin/64][tap][64] bytes padded to a multiple
+ * of 128 per row (d->K), k_real = taps * Cin, Cin % 64 == 0, bf16 output, a_scale + a_scale_rows. */
 typedef struct VkFp8Args {
     const float* a_scale;
     const float* w_scale;
@@ -93,9 +96,20 @@ typedef struct VkFp8Args {
     int32_t ld_mx;
     void* mx_out;
     int32_t ld_mx_out;
+    int32_t a_scale_rows; /* 0 / 1: a_scale is per row; n > 1: one scale per n consecutive rows (the per-image scales of
+                             vk_groupnorm_silu_fp8: n = H*W, or T*H*W for the temporal norm) */
 } VkFp8Args;
 int vk_gemm_fp8_mx(const VkGemmDesc* desc, const VkFp8Args* args, void* stream);
 int vk_gemm_fp8_rowstat_parts(const VkGemmDesc* d);
+
+/* GroupNorm(32)[+SiLU] with e4m3 output and ONE scale per image group (of frames_per_group images): y8 = e4m3(y / scale[g]), scale[g] =
+ * (max_c |a_c| max|x| + |b_c|) / 448 with y = a_c x + b_c the folded affine form -- an upper bound from the statistics pass (which also
+ * tracks max|x|), so no extra pass over the data; a conv output pixel sums taps of its own image only, so the scale factors out of the
+ * fp8 convolution (VkFp8Args.a_scale_rows). x2 != NULL: the input is the channel concat [x1 | x2] (C1 + C2 channels), as
+ * vk_groupnorm_silu_cat_bf16. stats_ws: floats, groups * 64 + n_img * ceil(S / 32) * 65.
+ * Reference: GroupNorm32 + SiLU of openaimodel.py:281-298, video_model.py:38-52. */
+int vk_groupnorm_silu_fp8(const void* x1, const void* x2, void* y8, float* scale_out, const float* gamma, const float* beta, float* stats_ws,
+                          int32_t n_img, int32_t S, int32_t C1, int32_t C2, int32_t frames_per_group, float eps, int32_t silu, void* stream);
 
 /* LayerNorm fused with per-row dynamic fp8 quantisation: y = LN(x)*gamma + beta (as vk_layernorm_bf16), scale[r] = max|y[r]| / 448,
  * q[r] = e4m3(y[r] / scale[r]) -- one pass, the normalised tensor is never written in bf16 (FeedForward input of the fp8 configuration:

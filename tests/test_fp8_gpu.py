@@ -218,6 +218,127 @@ def test_feedforward_fp8_no_quantisation_pass(dim, M):
     assert torch.allclose(st.t.sum(0)[:, 0], o.sum(1), rtol=1e-3, atol=1e-2 * o.abs().mean().item() * dim ** 0.5)
 
 
+def _gn_ref(x, gamma, beta, eps, silu, fpg):
+    n, S, Cc = x.shape
+    xg = x.float().view(n // fpg, fpg * S, Cc).permute(0, 2, 1)
+    y = torch.nn.functional.group_norm(xg, 32, gamma, beta, eps)
+    if silu:
+        y = torch.nn.functional.silu(y)
+    return y.permute(0, 2, 1).reshape(n, S, Cc)
+
+
+@pytest.mark.parametrize("n,S,C,C2,fpg,silu", [(4, 144, 320, 0, 1, True), (6, 100, 64, 0, 1, False), (6, 64, 192, 0, 3, True), (2, 576, 640, 320, 1, True),
+                                               (50, 16, 1280, 1280, 1, True), (10, 300, 320, 0, 5, True)])
+def test_groupnorm_fp8(n, S, C, C2, fpg, silu):
+    """GroupNorm[+SiLU] with e4m3 output and one scale per image group: the scale is an upper BOUND taken from the statistics pass
+    (no code may exceed 448 / be NaN), not looser than 8x the true maximum on this data (16x for a concat of two differently scaled
+    tensors: max|x| is taken over both), and every element is the e4m3 rounding of the exact result at that scale (<= 2^-4 relative, or
+    half a subnormal step)."""
+    ops = _ops()
+    x = (rnd(n, S, C).float() * torch.logspace(-1, 0.5, n)[:, None, None] * 1.5 + 0.7).to(BF16).cuda()
+    x2 = (rnd(n, S, C2, seed=7).float() * 0.8 - 0.3).to(BF16).cuda() if C2 else None
+    Ct = C + C2
+    gamma = (rnd(Ct, seed=1) * 0.4 + 1.0).cuda()
+    beta = (rnd(Ct, seed=2) * 0.3).cuda()
+    y8, sc = ops.groupnorm_fp8(x, gamma, beta, 1e-5, silu, fpg, x2=x2)
+    xin = x if x2 is None else torch.cat([x, x2], 2)
+    ref = _gn_ref(xin, gamma, beta, 1e-5, silu, fpg).cpu()
+    assert y8.shape == (n, S, Ct) and y8.dtype == torch.uint8 and sc.shape == (n // fpg,)
+    codes = y8.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.isfinite(codes).all()
+    s_img = sc.cpu().repeat_interleave(fpg)[:, None, None]
+    true_amax = ref.reshape(n // fpg, -1).abs().amax(1)
+    assert (sc.cpu() * 448.0 >= true_amax * 0.999).all(), "the scale must bound the data"
+    assert (sc.cpu() * 448.0 <= true_amax * (16.0 if C2 else 8.0) + 0.3).all(), "the bound is uselessly loose"
+    e = (codes * s_img - ref).abs()
+    assert (e <= (2 ** -4) * 1.03 * ref.abs() + s_img * 2 ** -10 + 3e-3 * ref.abs().mean()).all()
+    assert rel_l2(codes * s_img, ref) < 4e-2
+
+
+def _deq_conv_weight(pw, cout, cin, taps):
+    """packed e4m3 [Cout][Cin/64][tap][64] -> f32 [Cout][tap][Cin]"""
+    w = pw.wt[:cout, :taps * cin].cpu().view(torch.float8_e4m3fn).float() * pw.scale[:cout].cpu()[:, None]
+    return w.view(cout, cin // 64, taps, 64).permute(0, 2, 1, 3).reshape(cout, taps, cin)
+
+
+def _rand_fp8(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * 60).clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("n,H,W,cin,cout,fps", [(3, 9, 16, 320, 320, 1), (2, 18, 32, 640, 640, 1), (2, 12, 20, 960, 320, 1), (2, 6, 10, 64, 128, 1),
+                                                (4, 7, 9, 128, 320, 2), (1, 40, 33, 320, 640, 1)])
+def test_conv3x3_fp8_exact_against_dequantised_operands(n, H, W, cin, cout, fps):
+    """Implicit-GEMM 3x3 convolution on e4m3 activations with one scale per image (per `fps` images): exact against F.conv2d of the
+    dequantised operands (odd and even (slab, tap) unit counts, Cout with and without the 320-wide tile, zero padding at the borders)."""
+    ops = _ops()
+    a = _rand_fp8((n, H * W, cin), n + H + cin)
+    sc = (torch.rand(n // fps, generator=torch.Generator().manual_seed(5)) * 0.05 + 0.01)
+    w = rnd(cout, cin, 3, 3, scale=(9 * cin) ** -0.5, seed=1)
+    b = rnd(cout, seed=2)
+    pw = ops.pack_conv3x3_fp8(w, b)
+    r1 = rnd(n, H * W, cout, seed=3).to(BF16).cuda()
+    rv = rnd(n, cout, seed=4).cuda()
+    out = ops.conv3x3_fp8(a.view(torch.uint8).cuda(), sc.cuda(), pw, n, H, W, frames_per_scale=fps, rowvec=rv, res1=r1)
+    wd = _deq_conv_weight(pw, cout, cin, 9).view(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    xa = (a.float() * sc.repeat_interleave(fps)[:, None, None]).view(n, H, W, cin).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xa, wd, b, padding=1).permute(0, 2, 3, 1).reshape(n, H * W, cout)
+    ref = ref + rv.cpu()[:, None, :] + r1.float().cpu()
+    e = (out[..., :cout].float().cpu() - ref).abs()
+    assert out.shape[:2] == (n, H * W)
+    assert (e <= 2e-2 * ref.pow(2).mean().sqrt() + 1.6e-2 * ref.abs()).all(), f"max err {e.max().item()} rms {ref.pow(2).mean().sqrt().item()}"
+
+
+@pytest.mark.parametrize("B,T,S,cin,cout", [(2, 5, 40, 320, 320), (1, 25, 16, 64, 64), (2, 7, 33, 640, 1280), (1, 3, 300, 128, 320)])
+def test_conv_t3_fp8_exact_against_dequantised_operands(B, T, S, cin, cout):
+    """3x1x1 temporal convolution on e4m3 activations with one scale per clip, zero padding at the clip ends."""
+    ops = _ops()
+    a = _rand_fp8((B * T, S, cin), B + T + S)
+    sc = (torch.rand(B, generator=torch.Generator().manual_seed(6)) * 0.05 + 0.01)
+    w = rnd(cout, cin, 3, 1, 1, scale=(3 * cin) ** -0.5, seed=1)
+    b = rnd(cout, seed=2)
+    pw = ops.pack_conv_t3_fp8(w, b)
+    x0 = rnd(B * T, S, cout, seed=3).to(BF16).cuda()
+    out = ops.conv_t3_fp8(a.view(torch.uint8).cuda(), sc.cuda(), pw, T, S, alpha=0.7, res2=x0, beta=1.0)
+    wd = _deq_conv_weight(pw, cout, cin, 3).permute(0, 2, 1)                       # (Cout, Cin, 3)
+    xa = (a.float() * sc.repeat_interleave(T)[:, None, None]).view(B, T, S, cin).permute(0, 2, 3, 1).reshape(B * S, cin, T)
+    ref = torch.nn.functional.conv1d(xa, wd, b, padding=1).view(B, S, cout, T).permute(0, 3, 1, 2).reshape(B * T, S, cout)
+    ref = 0.7 * ref + x0.float().cpu()
+    e = (out[..., :cout].float().cpu() - ref).abs()
+    assert (e <= 2e-2 * ref.pow(2).mean().sqrt() + 1.6e-2 * ref.abs()).all(), f"max err {e.max().item()}"
+
+
+def test_video_resblock_fp8_convolutions():
+    """VideoResBlock (2-D ResBlock -> temporal ResBlock -> blend) with all four convolutions in fp8 against its own bf16 path: four
+    fp8 GEMMs on residual branches (~3.6e-2 each on the branch) -> rel-L2 of the block output <= 5e-2 (measured 2.7e-2); switching back
+    is bit-exact."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_blocks_gpu import _seed, _tok, _rand, _emb, T
+    from vista_amd.modules import attention
+    from vista_amd.modules.diffusionmodules.video_model import VideoResBlock
+    blk = VideoResBlock(channels=320, emb_channels=1280, dropout=0.0, out_channels=640, video_kernel_size=[3, 1, 1],
+                        merge_strategy="learned_with_images", merge_factor=0.5, dims=2)
+    _seed(blk, "blk", 3)
+    blk = blk.cuda().eval()
+    H, W = 18, 32
+    x = _tok(_rand((T, 320, H, W), 10))
+    emb_silu = torch.nn.functional.silu(_emb(5)).to(BF16).cuda()
+    with torch.no_grad():
+        base = blk(x, emb_silu, T, H, W).float().cpu()
+        attention.FP8["conv"] = True
+        try:
+            out = blk(x, emb_silu, T, H, W).float().cpu()
+        finally:
+            attention.FP8["conv"] = False
+        again = blk(x, emb_silu, T, H, W).float().cpu()
+    r = rel_l2(out, base)
+    print(f"[parity] VideoResBlock 320->640 fp8 convolutions vs bf16: rel-L2 {r:.3e}")
+    assert torch.isfinite(out).all() and r <= 5e-2
+    assert torch.equal(again, base)
+
+
 def test_fp8_rejects_bad_arguments():
     ops = _ops()
     pw = ops.pack_linear_fp8(rnd(64, 64), None)
@@ -231,9 +352,10 @@ def test_fp8_rejects_bad_arguments():
 
 
 def test_unet_with_fp8_feedforward_vs_reference_golden():
-    """BASELINE config 5 (first stage): the FeedForward GEMMs of every transformer block in fp8, everything else bf16.
-    Re-stated tolerance against the fp32 reference golden: relative L2 <= 7e-2 (measured 5.4e-2: 96 fp8 GEMMs with 3-bit
-    mantissas at ~3.6e-2 each on their residual branches; bf16 path: <= 2.5e-2, measured 1.4e-2)."""
+    """BASELINE config 5: the FeedForward GEMMs of every transformer block in fp8, then additionally every ResBlock convolution.
+    Re-stated tolerances against the fp32 reference golden: FeedForward only: relative L2 <= 7e-2 (measured 5.4e-2: 96 fp8 GEMMs with
+    3-bit mantissas at ~3.6e-2 each on their residual branches; bf16 path: <= 2.5e-2, measured 1.4e-2); FeedForward + convolutions
+    (another ~90 fp8 GEMMs): <= 1e-1 (measured 7.4e-2)."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
@@ -252,5 +374,13 @@ def test_unet_with_fp8_feedforward_vs_reference_golden():
     e8, eb = rl(out, g["out"]), rl(base, g["out"])
     print(f"[parity] UNet tiny, fp8 FeedForward: rel-L2 {e8:.3e} vs reference (bf16 path {eb:.3e}; fp8 vs bf16 {rl(out, base):.3e})")
     assert e8 <= 7e-2 and eb <= 2.5e-2
+    attention.FP8["feedforward"] = attention.FP8["conv"] = True
+    try:
+        out_c = net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=g["T"]).float().cpu()
+    finally:
+        attention.FP8["feedforward"] = attention.FP8["conv"] = False
+    e8c = rl(out_c, g["out"])
+    print(f"[parity] UNet tiny, fp8 FeedForward + convolutions: rel-L2 {e8c:.3e} vs reference (vs bf16 {rl(out_c, base):.3e})")
+    assert torch.isfinite(out_c).all() and e8c <= 1e-1
     again = net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=g["T"]).float().cpu()
     assert torch.equal(again, base), "switching fp8 off must restore the bf16 path bit for bit"

@@ -18,7 +18,8 @@ _f32 = C.c_float
 
 
 class VkFp8Args(C.Structure):
-    _fields_ = [("a_scale", _vp), ("w_scale", _vp), ("k_real", _i32), ("a_mx", _vp), ("ld_mx", _i32), ("mx_out", _vp), ("ld_mx_out", _i32)]
+    _fields_ = [("a_scale", _vp), ("w_scale", _vp), ("k_real", _i32), ("a_mx", _vp), ("ld_mx", _i32), ("mx_out", _vp), ("ld_mx_out", _i32),
+                ("a_scale_rows", _i32)]
 
 
 class VkGemmDesc(C.Structure):
@@ -47,6 +48,7 @@ SIGNATURES = {
     "vk_gemm_fp8_mx": [C.POINTER(VkGemmDesc), C.POINTER(VkFp8Args), _vp],
     "vk_gemm_fp8_rowstat_parts": [C.POINTER(VkGemmDesc)],
     "vk_layernorm_quant_fp8": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
+    "vk_groupnorm_silu_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_temporal_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],

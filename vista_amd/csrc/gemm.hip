@@ -98,6 +98,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
 
     const uint16_t* __restrict__ Ag = (const uint16_t*)p.A;
     const uint16_t* __restrict__ Wg = (const uint16_t*)p.Wt;
+    // address of the zero word that out-of-image taps read: formed ONCE and made opaque -- left to itself the compiler re-derives it in
+    // every K-step (s_getpc + s_load_dwordx2 of the GOT entry + s_waitcnt lgkmcnt(0), which also drains the wave's LDS reads)
+    const uint16_t* zsrc = (const uint16_t*)&g_zero16;
+    asm volatile("" : "+s"(zsrc));
 
     // ---- per-thread global->LDS staging assignment: chunk lc of rows lr + 32*i ----
     const int lc = tid & 7;
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
                 const int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
                 const bool ok = a_ok[i] && iy >= 0 && iy < He && ix >= 0 && ix < We;
                 const int sy = iy >> sh, sx = ix >> sh;
-                const uint16_t* src = ok ? aptr[i] + ((size_t)(sy * p.Wd + sx) * p.Cin + c0) : (const uint16_t*)&g_zero16;
+                const uint16_t* src = ok ? aptr[i] + ((size_t)(sy * p.Wd + sx) * p.Cin + c0) : zsrc;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         } else if (AMODE == AMODE_CONV3D) {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
                 const int t = a_x0[i] >> 12, ox = a_x0[i] & 4095;
                 const int tt = t + kt3 - 1, iy = oy + ky - 1, ix = ox + kx - 1;
                 const bool ok = a_ok[i] && tt >= 0 && tt < p.T && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
-                const uint16_t* src = ok ? aptr[i] + (((size_t)(fr + kt3 - 1) * p.H + iy) * p.Wd + ix) * p.Cin + c0 : (const uint16_t*)&g_zero16;
+                const uint16_t* src = ok ? aptr[i] + (((size_t)(fr + kt3 - 1) * p.H + iy) * p.Wd + ix) * p.Cin + c0 : zsrc;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         } else {
@@ -222,9 +226,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             for (int i = 0; i < AP; ++i) {
                 const int t = a_y0[i] + dt;
                 const uint16_t* src = aptr[i] + ((ptrdiff_t)dt * p.S * p.Cin + c0);
-                if (t < 0) src = hprev ? hprev + (a_x0[i] + c0) : (const uint16_t*)&g_zero16;
-                if (t >= p.T) src = hnext ? hnext + (a_x0[i] + c0) : (const uint16_t*)&g_zero16;
-                if (!a_ok[i]) src = (const uint16_t*)&g_zero16;
+                if (t < 0) src = hprev ? hprev + (a_x0[i] + c0) : zsrc;
+                if (t >= p.T) src = hnext ? hnext + (a_x0[i] + c0) : zsrc;
+                if (!a_ok[i]) src = zsrc;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
             }
         }

@@ -26,7 +26,8 @@ typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 __device__ uint4 g_zero16_f8;
 
 struct F8Args {
-    const float* a_scale;  // [M] per-row activation scale, or NULL (then a_mx)
+    const float* a_scale;  // per-row activation scale [M] (a_div <= 1) or one per a_div consecutive rows [ceil(M / a_div)], or NULL (then a_mx)
+    int a_div;
     const float* w_scale;  // [N padded] per-output-channel weight scale (GEGLU: in packed row order)
     int K;                 // real K (multiple of 16); p.K = weight row stride in bytes (multiple of 128, zero-filled past K)
     const uint8_t* a_mx;   // E8M0 block scales of the activations, [M][ld_mx] bytes, one per 32 K-elements, or NULL
@@ -48,12 +49,13 @@ __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float 
     return (uint32_t)v;
 }
 
-template <int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, int FN>
+template <int AMODE, int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, int FN>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp8_kernel(const VkGemmDesc p, const F8Args q) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     constexpr int NT = WM * WN * 64;
     constexpr int RPP = NT / 8;
-    constexpr int AP = BM / RPP, WP = BN / RPP;
+    constexpr int AP = BM / RPP, WP = (BN + RPP - 1) / RPP;  // the last W pass may be partial (320 rows, 128 per pass)
+    static_assert(BM % RPP == 0 && BN % 8 == 0, "A rows must be a multiple of the staging pass, W rows of a wave's 8-row slice");
     constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
     constexpr int FX = FN, FY = FM;  // X = weights (MFMA row operand), Y = activations
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -74,33 +76,88 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
 
     const uint8_t* __restrict__ Ag = (const uint8_t*)p.A;
     const uint8_t* __restrict__ Wg = (const uint8_t*)p.Wt;
+    const uint8_t* zsrc = (const uint8_t*)&g_zero16_f8;  // formed once and opaque: see gemm.hip
+    asm volatile("" : "+s"(zsrc));
 
     const int lc = tid & 7, lr = tid >> 3;
     const int lsrc = lc ^ ((lr >> 1) & 7);  // logical 16-B chunk this lane fetches so that the swizzled image lands (gemm.hip)
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    const uint8_t* wptr[WP];
+    // 32-bit byte offsets from the (uniform) tensor bases: half the address registers of per-lane pointers (the entry point checks that
+    // both tensors are smaller than 4 GiB)
+    uint32_t woff[WP];
 #pragma unroll
-    for (int i = 0; i < WP; ++i) wptr[i] = Wg + (size_t)(n0 + lr + RPP * i) * p.K + lsrc * 16;
-    const uint8_t* aptr[AP];
+    for (int i = 0; i < WP; ++i) woff[i] = (uint32_t)(n0 + lr + RPP * i) * (uint32_t)p.K + lsrc * 16;
+    // A-row state. Implicit-GEMM loaders (AMODE_CONV3X3 / AMODE_TEMPORAL3: the ResBlock convolutions on fp8 GroupNorm output): the K axis is
+    // the bf16 kernels' [Cin/64][tap][64] order (gemm.hip), in bytes; a 128-byte K-step covers TWO (slab, tap) units, and since a lane always
+    // stages the same 16-byte chunk of a row, the unit it works on (first or second of the step) and its 16-channel offset inside the unit
+    // are per-lane constants: each lane steps its own (tap, slab) pair by two units per K-step.
+    constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
+    uint32_t aoff[AP];
+    int a_y0[AP], a_x0[AP];  // conv: (row, column) of tap (0, 0) / frame index; rows past M get coordinates no tap can bring into range
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         int m = m0 + lr + RPP * i;
-        if (m >= p.M) m = p.M - 1;
-        aptr[i] = Ag + (size_t)m * p.lda + lsrc * 16;
+        const bool row_ok = m < p.M;
+        if (!row_ok) m = p.M - 1;
+        if (AMODE == AMODE_DENSE) {
+            aoff[i] = (uint32_t)m * (uint32_t)p.lda + lsrc * 16;
+            a_y0[i] = a_x0[i] = 0;
+        } else if (AMODE == AMODE_CONV3X3) {  // stride 1, pad 1
+            const int hw = p.H * p.Wd;
+            const int img = m / hw;
+            const int rem = m - img * hw;
+            const int oy = rem / p.Wd;
+            a_y0[i] = row_ok ? oy - 1 : -(1 << 20);
+            a_x0[i] = rem - oy * p.Wd - 1;
+            aoff[i] = (uint32_t)img * (uint32_t)(hw * p.Cin) + (lsrc & 3) * 16;
+        } else {  // TEMPORAL3: m = (b*T + t)*S + s, zero padding at the clip ends
+            a_y0[i] = row_ok ? (m / p.S) % p.T : -(1 << 20);
+            a_x0[i] = 0;
+            aoff[i] = (uint32_t)m * (uint32_t)p.Cin + (lsrc & 3) * 16;
+        }
     }
+    int tap_l = lsrc >> 2, cbase_l = 0;  // this lane's next (tap, channel base); units past the last slab (odd unit count) read zeros
 
     auto dma_tile = [&](int kt, int stage) {
         const int k0 = kt * 128;
         char* sA = smem + stage * STAGE_BYTES + wave_u * 1024;
         char* sW = sA + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < WP; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(wptr[i] + k0), (lptr_t)(sW + i * RPP * 128), 16, 0, 0);
-        const bool inside = k0 + lsrc * 16 < q.K;  // K tail (K = 320: 2.5 K-steps): chunks past the row end are zero-filled
+        for (int i = 0; i < WP; ++i)
+            if (RPP * (i + 1) <= BN || RPP * i + 8 * wave_u < BN)  // wave-uniform: waves past the tile's last row skip the partial pass
+                __builtin_amdgcn_global_load_lds((gptr_t)(Wg + (woff[i] + (uint32_t)k0)), (lptr_t)(sW + i * RPP * 128), 16, 0, 0);
+        if (AMODE == AMODE_DENSE) {
+            const bool inside = k0 + lsrc * 16 < q.K;  // K tail (K = 320: 2.5 K-steps): chunks past the row end are zero-filled
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            const uint8_t* src = inside ? aptr[i] + k0 : (const uint8_t*)&g_zero16_f8;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+            for (int i = 0; i < AP; ++i) {
+                const uint8_t* src = inside ? Ag + (aoff[i] + (uint32_t)k0) : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+            }
+        } else if (AMODE == AMODE_CONV3X3) {
+            const bool inside = cbase_l < p.Cin;
+            const int ky = tap_l / 3, kx = tap_l - ky * 3;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int iy = a_y0[i] + ky, ix = a_x0[i] + kx;
+                const bool ok = inside && iy >= 0 && iy < p.H && ix >= 0 && ix < p.Wd;
+                const uint8_t* src = ok ? Ag + (aoff[i] + (uint32_t)((iy * p.Wd + ix) * p.Cin + cbase_l)) : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+            }
+        } else {
+            const bool inside = cbase_l < p.Cin;
+            const int dt = tap_l - 1;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                const int t = a_y0[i] + dt;
+                const bool ok = inside && t >= 0 && t < p.T;
+                const uint8_t* src = ok ? Ag + (aoff[i] + (uint32_t)(dt * p.S * p.Cin + cbase_l)) : zsrc;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sA + i * RPP * 128), 16, 0, 0);
+            }
+        }
+        if (AMODE != AMODE_DENSE) {
+            tap_l += 2;
+            if (tap_l >= NTAPS) { tap_l -= NTAPS; cbase_l += 64; }
         }
     };
 
@@ -148,6 +205,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
 #pragma unroll
             for (int fj = 0; fj < FY; ++fj) ynext[fj] = (int)(*(const uint32_t*)(q.a_mx + mxoff[fj] + ktn * 4) >> (8 * lh));
         }
+        if constexpr (WM * WN == 16 && FX * FY > 4) {
+            // sixteen 32x160 wave tiles (N = 320 convolutions): 5 + 1 eight-register fragments next to 80 accumulators do not fit 128
+            // VGPRs at once -- the activation fragment stays, the weight fragments pass through one at a time
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                i32x8_t yf[FY];
+#pragma unroll
+                for (int f = 0; f < FY; ++f) yf[f] = load_frag(sb + yrow_off + f * 32 * 128, ks);
+#pragma unroll
+                for (int fi = 0; fi < FX; ++fi) {
+                    const i32x8_t xf = load_frag(sb + xrow_off + fi * 32 * 128, ks);
+#pragma unroll
+                    for (int fj = 0; fj < FY; ++fj)
+                        acc[fi][fj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xf, yf[fj], acc[fi][fj], 0, 0, 0, 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             i32x8_t xf[FX], yf[FY];
@@ -186,7 +261,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
 #pragma unroll
     for (int fj = 0; fj < FY; ++fj) {
         const int m = m0 + wm * MW + fj * 32 + l31;
-        const float sa = AMX ? 1.f : q.a_scale[m < p.M ? m : p.M - 1];  // MX activations were scaled inside the MFMA
+        const int mc = m < p.M ? m : p.M - 1;
+        const float sa = AMX ? 1.f : q.a_scale[AMODE != AMODE_DENSE ? mc / q.a_div : mc];  // convolutions: one scale per image group  // MX activations were scaled inside the MFMA
 #pragma unroll
         for (int fi = 0; fi < FX; ++fi)
 #pragma unroll
@@ -253,11 +329,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
     gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn);
 }
 
-template <int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, int FN>
+template <int AMODE, int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, int FN>
 int launch_cfg(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tiles = ((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, OUT_F32, AMX, WM, WN, FM, FN>), dim3(tiles), dim3(WM * WN * 64), 0, stream, *d, q);
+    hipLaunchKernelGGL((gemm_fp8_kernel<AMODE, EPI, OUT_F32, AMX, WM, WN, FM, FN>), dim3(tiles), dim3(WM * WN * 64), 0, stream, *d, q);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
@@ -267,9 +343,17 @@ int fp8_cfg(const VkGemmDesc* d);
 template <int EPI, bool OUT_F32, bool AMX>
 int launch(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
     const int cfg = fp8_cfg(d);
-    if (cfg == 4 && EPI != EPI_GEGLU) return launch_cfg<EPI, OUT_F32, AMX, 4, 2, 2, 5>(d, q, stream);
-    if (cfg >= 3) return launch_cfg<EPI, OUT_F32, AMX, 4, 4, 2, 2>(d, q, stream);  // sixteen 64x64 wave tiles, 4 waves per SIMD (as in gemm.hip)
-    return launch_cfg<EPI, OUT_F32, AMX, 2, 2, 2, 2>(d, q, stream);
+    if (cfg == 4 && EPI != EPI_GEGLU) return launch_cfg<AMODE_DENSE, EPI, OUT_F32, AMX, 4, 2, 2, 5>(d, q, stream);
+    if (cfg >= 3) return launch_cfg<AMODE_DENSE, EPI, OUT_F32, AMX, 4, 4, 2, 2>(d, q, stream);  // sixteen 64x64 wave tiles, 4 waves per SIMD (as in gemm.hip)
+    return launch_cfg<AMODE_DENSE, EPI, OUT_F32, AMX, 2, 2, 2, 2>(d, q, stream);
+}
+
+// implicit-GEMM convolutions: 256x320 block tiles as eight 64x160 wave tiles where Cout is a multiple of 320 (every UNet level; the
+// sixteen-wave 32x160 form of the bf16 kernels does not fit eight-register fp8 fragments into 128 VGPRs), else 256x256
+template <int AMODE>
+int launch_conv(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
+    if (d->N % 320 == 0) return launch_cfg<AMODE, EPI_LINEAR, false, false, 4, 2, 2, 5>(d, q, stream);
+    return launch_cfg<AMODE, EPI_LINEAR, false, false, 4, 4, 2, 2>(d, q, stream);
 }
 
 // one wave per row: amax -> scale = amax / 448, q = e4m3(x / scale)
@@ -335,14 +419,29 @@ int fp8_cfg(const VkGemmDesc* d) {  // the tile variant launch<>() picks (1 = 12
 int gemm_fp8_entry(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
     if (!d || !d->A || !d->Wt || !d->out || (!q.a_scale && !q.a_mx) || (q.a_scale && q.a_mx) || !q.w_scale) return VK_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % 128) != 0 || (d->N % 4) != 0 || q.K <= 0 || q.K > d->K || (q.K % 16) != 0 ||
-        d->lda < q.K || (d->lda % 16) != 0 || d->amode != AMODE_DENSE || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 7)
+        d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 7 || q.a_div < 0)
         return VK_EINVAL;
+    const bool conv = d->amode == AMODE_CONV3X3 || d->amode == AMODE_TEMPORAL3;
+    if ((long long)(d->N + 320) * d->K >= (1LL << 32)) return VK_EINVAL;  // 32-bit offsets in the loaders
+    if (conv ? (q.a_div < 1 || (long long)d->M * d->Cin >= (1LL << 32)) : (q.a_div > 1 || (long long)d->M * d->lda >= (1LL << 32))) return VK_EINVAL;
+    if (!conv && (d->amode != AMODE_DENSE || d->lda < q.K || (d->lda % 16) != 0)) return VK_EINVAL;
+    if (conv) {  // fp8 GroupNorm output -> ResBlock convolution: stride 1, pad 1, bf16 output, per-image-group activation scales
+        const int nt = d->amode == AMODE_CONV3X3 ? 9 : 3;
+        if (d->Cin <= 0 || (d->Cin % 64) != 0 || q.K != nt * d->Cin || q.a_mx || q.mx_out || d->epi != EPI_LINEAR || d->out_f32 || d->rowstat_out)
+            return VK_EINVAL;
+        if (d->amode == AMODE_CONV3X3 && (d->H <= 0 || d->Wd <= 0 || d->stride != 1 || d->ups != 1 || d->asym_pad || d->Hout != d->H ||
+                                          d->Wout != d->Wd || d->M % (d->H * d->Wd) != 0))
+            return VK_EINVAL;
+        if (d->amode == AMODE_TEMPORAL3 && (d->T <= 0 || d->S <= 0 || d->halo_prev || d->halo_next || d->M % (d->T * d->S) != 0)) return VK_EINVAL;
+    }
     if ((d->rowvec || d->rowvec2) && d->rows_per_vec <= 0) return VK_EINVAL;
     if (d->ln_stats || d->A2 || (d->rowvec2 && !d->res2)) return VK_EINVAL;  // bf16-GEMM-only features
     if (d->rowstat_out && (d->epi != EPI_LINEAR || d->out_f32)) return VK_EINVAL;
     if (q.a_mx && (q.ld_mx * 32 < d->K || (q.ld_mx % 4) != 0 || (q.K % 32) != 0)) return VK_EINVAL;  // one dword of block scales per 128-byte K-step
     if (q.mx_out && (d->epi != EPI_GEGLU || ((d->N >> 1) % 32) != 0 || (d->ldc % 16) != 0 || q.ld_mx_out * 32 < (d->N >> 1))) return VK_EINVAL;
     const bool f32 = d->out_f32 != 0;
+    if (d->amode == AMODE_CONV3X3) return launch_conv<AMODE_CONV3X3>(d, q, stream);
+    if (d->amode == AMODE_TEMPORAL3) return launch_conv<AMODE_TEMPORAL3>(d, q, stream);
     if (q.a_mx) return (d->epi == EPI_LINEAR && !f32) ? launch<EPI_LINEAR, false, true>(d, q, stream) : VK_EINVAL;  // the FF-out GEMM
     if (d->epi == EPI_LINEAR) return f32 ? launch<EPI_LINEAR, true, false>(d, q, stream) : launch<EPI_LINEAR, false, false>(d, q, stream);
     if (d->epi == EPI_GEGLU && !f32 && (d->N % 32) == 0) return launch<EPI_GEGLU, false, false>(d, q, stream);
@@ -351,13 +450,13 @@ int gemm_fp8_entry(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
 }  // namespace
 
 extern "C" int vk_gemm_fp8(const VkGemmDesc* d, const float* a_scale, const float* w_scale, int32_t k_real, void* stream_) {
-    const F8Args q{a_scale, w_scale, k_real, nullptr, 0, nullptr, 0};
+    const F8Args q{a_scale, 0, w_scale, k_real, nullptr, 0, nullptr, 0};
     return gemm_fp8_entry(d, q, (hipStream_t)stream_);
 }
 
 extern "C" int vk_gemm_fp8_mx(const VkGemmDesc* d, const VkFp8Args* a, void* stream_) {
     if (!a) return VK_EINVAL;
-    const F8Args q{a->a_scale, a->w_scale, a->k_real, (const uint8_t*)a->a_mx, a->ld_mx, (uint8_t*)a->mx_out, a->ld_mx_out};
+    const F8Args q{a->a_scale, a->a_scale_rows, a->w_scale, a->k_real, (const uint8_t*)a->a_mx, a->ld_mx, (uint8_t*)a->mx_out, a->ld_mx_out};
     return gemm_fp8_entry(d, q, (hipStream_t)stream_);
 }
 

@@ -21,8 +21,12 @@ constexpr int GN_TOK = 128;  // tokens per workgroup
 // (thread partials -> LDS [r][channel] -> per-channel over r -> per-group over channels): bitwise reproducible.
 // Two-source form (x2 != NULL): the tensor is the channel concat [x | x2] of C1 + (C - C1) channels (UNet skip concat, never
 // materialised); every thread owns one fixed 16-B channel chunk, so the source choice is a per-thread constant.
+// AMAX (fp8 output mode of the apply pass): the workgroup also writes max|x| of its elements to amax_part[img][chunk] (plain store: no
+// atomics, nothing to clear); the apply pass reduces the partials of its image group.
+template <bool AMAX>
 __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1, float* __restrict__ partial, int S, int C,
-                                int CG, int R, int tok_per_wg) {
+                                int CG, int R, int tok_per_wg, float* __restrict__ amax_part) {
+    __shared__ float wave_amax[16];
     extern __shared__ float lds[];  // [2][R][C]
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
@@ -32,6 +36,7 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* 
     const int cpg = C >> 5;
     float* lsum = lds;
     float* lsq = lds + R * C;
+    float amx = 0.f;
     if (r < R) {
         float sm[8], sq[8];
 #pragma unroll
@@ -49,7 +54,11 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* 
                 float f[8];
                 unpack8(v[u], f);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] = fmaf(f[e], f[e], sq[e]); }
+                for (int e = 0; e < 8; ++e) {
+                    sm[e] += f[e];
+                    sq[e] = fmaf(f[e], f[e], sq[e]);
+                    if (AMAX) amx = fmaxf(amx, fabsf(f[e]));
+                }
             }
         }
         for (; t < tok1; t += R) {
@@ -57,7 +66,11 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* 
             float f[8];
             unpack8(v, f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { sm[e] += f[e]; sq[e] = fmaf(f[e], f[e], sq[e]); }
+            for (int e = 0; e < 8; ++e) {
+                sm[e] += f[e];
+                sq[e] = fmaf(f[e], f[e], sq[e]);
+                if (AMAX) amx = fmaxf(amx, fabsf(f[e]));
+            }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -65,7 +78,17 @@ __global__ void gn_stats_kernel(const uint16_t* __restrict__ x, const uint16_t* 
             lsq[r * C + chunk * 8 + e] = sq[e];
         }
     }
+    if (AMAX) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amx = fmaxf(amx, __shfl_xor(amx, o, 64));
+        if ((tid & 63) == 0) wave_amax[tid >> 6] = amx;
+    }
     __syncthreads();
+    if (AMAX && tid == 0) {
+        float m = wave_amax[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, wave_amax[w]);
+        amax_part[(size_t)img * gridDim.x + blockIdx.x] = m;
+    }
     for (int c = tid; c < C; c += blockDim.x) {  // per-channel totals over the R token lanes, fixed order
         float a = 0.f, b = 0.f;
         for (int rr = 0; rr < R; ++rr) { a += lsum[rr * C + c]; b += lsq[rr * C + c]; }
@@ -170,6 +193,91 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
         }
         *(uint4*)(y + base + (size_t)t * C) = pack8(f);
     }
+}
+
+// GroupNorm(+SiLU) apply with fp8 (e4m3) output and ONE scale per image group, for the fp8 convolutions of BASELINE config 5: a conv
+// output pixel sums taps of its own image only, so a per-image activation scale factors out of the implicit-GEMM K-sum (a per-token
+// scale would not). The scale needs no extra pass: with max|x| of the image group (gn_stats_kernel<true>) every channel's output is
+// bounded by |a_c| max|x| + |b_c| (y = a_c x + b_c, a_c = gamma_c rstd, b_c = beta_c - mean a_c), SiLU only shrinks magnitudes above
+// 0.2785, and e4m3 is a floating format, so a bound that is loose by a small factor costs no precision. Every workgroup of the group
+// derives the same scale (fixed-order max over the C channels); workgroup (0, first image of the group) publishes it.
+__global__ void gn_apply_fp8_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1, uint8_t* __restrict__ y, float* __restrict__ scale_out,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ stats,
+                                    const float* __restrict__ amax_part, int S, int C, int CG, int R, int frames_per_group, float inv_cnt,
+                                    float eps, int do_silu, int tok_per_wg) {
+    __shared__ unsigned bound_bits, xmax_bits;
+    const int tid = threadIdx.x;
+    const int img = blockIdx.y;
+    const int tok0 = blockIdx.x * tok_per_wg;
+    const int tok1 = min(tok0 + tok_per_wg, S);
+    const int chunk = tid % CG, r = tid / CG;
+    const int cpg = C >> 5;
+    const int grp = img / frames_per_group;
+    const float* st = stats + (size_t)grp * 64;  // [32 sums | 32 sums of squares]
+    if (tid == 0) { bound_bits = 0u; xmax_bits = 0u; }
+    __syncthreads();
+    {   // max|x| of the image group from the statistics pass' per-workgroup maxima (frames_per_group x chunks values)
+        const int nparts = frames_per_group * gridDim.x;
+        const float* pp = amax_part + (size_t)grp * nparts;
+        float m = 0.f;
+        for (int i = tid; i < nparts; i += blockDim.x) m = fmaxf(m, pp[i]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) atomicMax(&xmax_bits, __float_as_uint(m));  // LDS, one per wave; a maximum does not depend on the order
+    }
+    __syncthreads();
+    const float xmax = __uint_as_float(xmax_bits);
+    float a[8], b[8];
+    if (r < R) {
+        float bound = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = chunk * 8 + e;
+            const int g = c / cpg;
+            const float mean = st[g] * inv_cnt;
+            const float var = fmaxf(st[32 + g] * inv_cnt - mean * mean, 0.f);
+            a[e] = gamma[c] * rsqrtf(var + eps);
+            b[e] = beta[c] - mean * a[e];
+            bound = fmaxf(bound, fmaf(fabsf(a[e]), xmax, fabsf(b[e])));
+        }
+        if (r == 0) atomicMax(&bound_bits, __float_as_uint(bound));
+    }
+    __syncthreads();
+    if (r >= R) return;
+    float bound = __uint_as_float(bound_bits) * 1.0001f;  // fp32 rounding of a x + b against the bound
+    if (do_silu) bound = fmaxf(bound, 0.2785f);
+    bound = fmaxf(bound, 1e-20f);
+    const float sc = bound * (1.f / 448.f);
+    const float inv = 448.f / bound;
+    if (blockIdx.x == 0 && tid == 0 && img % frames_per_group == 0) scale_out[grp] = sc;
+    const size_t base = ((size_t)img * S) * C + chunk * 8;
+    const bool second = x2 != nullptr && chunk * 8 >= C1;
+    const int ld = x2 == nullptr ? C : (second ? C - C1 : C1);
+    const uint16_t* xs = (second ? x2 + (chunk * 8 - C1) : x + chunk * 8) + ((size_t)img * S) * ld;
+    auto emit = [&](const uint4& v, int t) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float w = fmaf(f[e], a[e], b[e]);
+            if (do_silu) w = silu_f(w);
+            f[e] = fminf(fmaxf(w * inv, -448.f), 448.f);  // the cvt yields NaN above 448, it does not saturate
+        }
+        int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+        int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+        *(int2*)(y + base + (size_t)t * C) = make_int2(lo, hi);
+    };
+    int t = tok0 + r;
+    for (; t + 3 * R < tok1; t += 4 * R) {  // 4 independent 16-B loads in flight per thread
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(xs + (size_t)(t + u * R) * ld);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) emit(v[u], t + u * R);
+    }
+    for (; t < tok1; t += R) emit(*(const uint4*)(xs + (size_t)t * ld), t);
 }
 
 // LayerNorm: one wave per row, NCH 16-B chunks per lane (C <= 512*NCH). Two-pass (mean, centred variance) in
@@ -354,14 +462,18 @@ inline bool gn_geom(int n_img, int S, int C, int fpg, GnGeom& g) {
 
 namespace {
 int gn_stats(const void* x, const void* x2, int C1, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group,
-             void* stream_) {
+             void* stream_, float* amax_part = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
     GnGeom g;
     if (!x || !sums || !partial_ws || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
     dim3 grid(g.nchunks, n_img);
     const size_t lds_bytes = (size_t)2 * g.R * C * sizeof(float);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, partial_ws, S, C, g.CG,
-                       g.R, g.tok);
+    if (amax_part)
+        hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, partial_ws, S, C,
+                           g.CG, g.R, g.tok, amax_part);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, partial_ws, S, C,
+                           g.CG, g.R, g.tok, (float*)nullptr);
     VK_CHECK_LAUNCH();
     const int nparts = frames_per_group * g.nchunks;
     if (nparts <= 256) {
@@ -414,6 +526,29 @@ extern "C" int vk_groupnorm_silu_cat_bf16(const void* x1, const void* x2, void* 
     if (rc != VK_OK) return rc;
     const float count = (float)(C / 32) * (float)S * (float)frames_per_group;
     return gn_apply(x1, x2, C1, y, gamma, beta, stats_ws, n_img, S, C, frames_per_group, count, eps, silu, stream_);
+}
+
+extern "C" int vk_groupnorm_silu_fp8(const void* x1, const void* x2, void* y8, float* scale_out, const float* gamma, const float* beta,
+                                     float* stats_ws, int32_t n_img, int32_t S, int32_t C1, int32_t C2, int32_t frames_per_group, float eps,
+                                     int32_t silu, void* stream_) {
+    if (!x1 || !y8 || !scale_out || !gamma || !beta || !stats_ws || frames_per_group <= 0 || n_img <= 0 || C1 <= 0 || C2 < 0 || (C1 % 8) != 0 ||
+        (C2 % 8) != 0 || (x2 == nullptr) != (C2 == 0))
+        return VK_EINVAL;
+    const int C = C1 + C2;
+    GnGeom g;
+    if (!gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
+    // workspace: [groups][64] sums | [n_img][chunks] per-workgroup max|x| | [n_img][chunks][64] partial sums
+    float* amax = stats_ws + (size_t)g.ngroups * 64;
+    float* partial = amax + (size_t)n_img * g.nchunks;
+    int rc = gn_stats(x1, x2, C1, stats_ws, partial, n_img, S, C, frames_per_group, stream_, amax);
+    if (rc != VK_OK) return rc;
+    const float count = (float)(C / 32) * (float)S * (float)frames_per_group;
+    dim3 grid(g.nchunks, n_img);
+    hipLaunchKernelGGL(gn_apply_fp8_kernel, grid, dim3(g.threads), 0, (hipStream_t)stream_, (const uint16_t*)x1, (const uint16_t*)x2, C1, (uint8_t*)y8,
+                       scale_out, gamma, beta, (const float*)stats_ws, (const float*)amax, S, C, g.CG, g.R, frames_per_group, 1.f / count, eps, silu,
+                       g.tok);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
 }
 
 extern "C" int vk_rowstats_bf16(const void* x, float* stats, int32_t rows, int32_t C, int64_t ldx, void* stream_) {

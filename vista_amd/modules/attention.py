@@ -81,7 +81,8 @@ class GEGLU(nn.Module):
 
 # BASELINE config 5 opt-in (off by default; the headline path is bf16): run the FeedForward GEMMs -- GEGLU in-projection and
 # out-projection, 32 % of the UNet's FLOPs -- in fp8 e4m3 with per-token activation scales and per-channel weight scales.
-FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1"}
+# "conv": additionally the ResBlock convolutions (2-D 3x3 and temporal 3x1x1) on e4m3 GroupNorm output (openaimodel.py ResBlock).
+FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1", "conv": os.environ.get("VISTA_FP8_CONV", "0") == "1"}
 
 
 class FeedForward(nn.Module, Packable):

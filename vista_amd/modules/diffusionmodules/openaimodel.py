@@ -11,7 +11,7 @@ from typing import Iterable
 import torch.nn as nn
 
 from ... import ops
-from ..attention import Packable
+from ..attention import FP8, Packable
 from .util import Dropout, SiLU, conv_nd, linear, normalization, timestep_embedding, zero_module
 
 
@@ -121,6 +121,10 @@ class ResBlock(TimestepBlock, Packable):
             pk["emb"] = ops.pack_linear(self.emb_layers[1].weight, self.emb_layers[1].bias, dev)
         if not isinstance(self.skip_connection, nn.Identity):
             pk["skip"] = ops.pack_linear(self.skip_connection.weight, self.skip_connection.bias, dev)
+        if FP8["conv"] and not self.full3d:
+            pc8 = ops.pack_conv3x3_fp8 if self.dims == 2 else ops.pack_conv_t3_fp8
+            pk["conv1_8"] = pc8(self.in_layers[2].weight, self.in_layers[2].bias, device=dev)
+            pk["conv2_8"] = pc8(self.out_layers[3].weight, self.out_layers[3].bias, device=dev)
         return pk
 
     def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, shard=None, T_global=None):
@@ -160,6 +164,21 @@ class ResBlock(TimestepBlock, Packable):
 
         def halo(t):
             return shard.halo_exchange(t) if (shard is not None and self.dims == 3) else (None, None)
+        if FP8["conv"] and shard is None and not self.full3d:
+            # BASELINE config 5: both convolutions in fp8 e4m3. The GroupNorm+SiLU pass writes e4m3 with one scale per image (per clip for the
+            # temporal norm) -- half the bytes it wrote before -- and the implicit-GEMM loaders stream those bytes; no quantisation pass.
+            if "conv1_8" not in pk:  # the switch was flipped after the bf16 pack was built
+                self.invalidate_packed()
+                pk = self.packed()
+            h8, hs = ops.groupnorm_fp8(x, gn1.weight, gn1.bias, gn1.eps, True, fpg, x2=xb)
+            if self.dims == 2:
+                h = ops.conv3x3_fp8(h8, hs, pk["conv1_8"], n_img, H, W, rowvec=emb_out)
+                h8, hs = ops.groupnorm_fp8(h, gn2.weight, gn2.bias, gn2.eps, True)
+                skip = x if "skip" not in pk else ops.linear(x, pk["skip"], x2=xb)
+                return ops.conv3x3_fp8(h8, hs, pk["conv2_8"], n_img, H, W, res1=skip)
+            h = ops.conv_t3_fp8(h8, hs, pk["conv1_8"], T, S, rowvec=emb_out)
+            h8, hs = ops.groupnorm_fp8(h, gn2.weight, gn2.bias, gn2.eps, True, fpg)
+            return ops.conv_t3_fp8(h8, hs, pk["conv2_8"], T, S, alpha=out_alpha, res2=x, beta=1.0)
         h = gnorm(x, gn1) if xb is None else ops.groupnorm_cat(x, xb, gn1.weight, gn1.bias, gn1.eps, silu=True)
         if self.dims == 2:
             h, _, _ = ops.conv3x3(h, pk["conv1"], n_img, H, W, rowvec=emb_out)

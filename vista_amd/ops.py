@@ -427,6 +427,23 @@ def pack_linear_fp8(weight, bias=None, device="cuda"):
     return _finish_pack_fp8(weight.detach().reshape(weight.shape[0], -1).float().cpu(), None if bias is None else bias.detach().float().cpu(), device)
 
 
+def pack_conv3x3_fp8(weight, bias=None, device="cuda"):
+    """nn.Conv2d weight [Cout][Cin][3][3] (Cin % 64 == 0) -> e4m3 [Cout][Cin/64][ky][kx][64], one scale per output channel."""
+    w = weight.detach().float().cpu().permute(0, 2, 3, 1).contiguous()
+    cout, _, _, cin = w.shape
+    if cin % 64:
+        raise ValueError("fp8 conv3x3 needs Cin % 64 == 0")
+    return _finish_pack_fp8(_slab_major(w.reshape(cout, 9, cin)), None if bias is None else bias.detach().float().cpu(), device)
+
+
+def pack_conv_t3_fp8(weight, bias=None, device="cuda"):
+    """nn.Conv3d weight [Cout][Cin][3][1][1] (Cin % 64 == 0) -> e4m3 [Cout][Cin/64][kt][64], one scale per output channel."""
+    w = weight.detach().float().cpu()[:, :, :, 0, 0].permute(0, 2, 1).contiguous()
+    if w.shape[2] % 64:
+        raise ValueError("fp8 temporal conv needs Cin % 64 == 0")
+    return _finish_pack_fp8(_slab_major(w), None if bias is None else bias.detach().float().cpu(), device)
+
+
 def pack_geglu_fp8(weight, bias, device="cuda"):
     """GEGLU.proj in the value/gate-interleaved row order of pack_geglu, quantised per packed row."""
     w = weight.detach().float().cpu()
@@ -444,6 +461,66 @@ def quantize_rows_fp8(x):
     scale = torch.empty((M,), dtype=F32, device=x.device)
     check(_lib.load().vk_quantize_rows_fp8(_p(x2), _p(q), _p(scale), M, K, ldx, K, _stream()), "vk_quantize_rows_fp8")
     return q, scale
+
+
+def groupnorm_fp8(x, gamma, beta, eps, silu, frames_per_group=1, x2=None):
+    """GroupNorm(32)[+SiLU] with e4m3 output and one scale per image group: x (n_img, S, C) bf16 [x2: second tensor of a channel concat]
+    -> (y8 uint8 (n_img, S, C[+C2]), scale f32 (n_img / frames_per_group,)), GN(x) ~= y8 * scale[image group]. The scale is an upper bound
+    from the statistics pass (include/vista_hip.h: vk_groupnorm_silu_fp8), not a measured maximum."""
+    _need(x, BF16, "x")
+    if not x.is_contiguous() or (x2 is not None and (not x2.is_contiguous() or x2.shape[:2] != x.shape[:2])):
+        raise ValueError("groupnorm_fp8: contiguous (n_img, S, C) inputs with equal n_img, S required")
+    n_img, S, c1 = x.shape
+    c2 = 0 if x2 is None else x2.shape[2]
+    ng = n_img // frames_per_group
+    y = torch.empty((n_img, S, c1 + c2), dtype=torch.uint8, device=x.device)
+    scale = torch.empty((ng,), dtype=F32, device=x.device)
+    ws = torch.empty(ng * 64 + n_img * ((S + 31) // 32) * 65, dtype=F32, device=x.device)
+    check(_lib.load().vk_groupnorm_silu_fp8(_p(x), _p(x2), _p(y), _p(scale), _p(gamma), _p(beta), _p(ws), n_img, S, c1, c2, frames_per_group,
+                                            float(eps), 1 if silu else 0, _stream()), "vk_groupnorm_silu_fp8")
+    return y, scale
+
+
+def _conv_fp8(d, x8, scale, rows_per_scale, pw, M, rowvec, rows_per_vec, res1, res2, alpha, beta):
+    out = torch.empty((M, pw.N), dtype=BF16, device=x8.device)
+    _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta)
+    d.K = pw.Kp
+    d.tile_cfg = 0
+    a = VkFp8Args()
+    a.a_scale, a.w_scale, a.k_real, a.a_scale_rows = _p(scale), _p(pw.scale), pw.K, rows_per_scale
+    check(_lib.load().vk_gemm_fp8_mx(C.byref(d), C.byref(a), _stream()), "vk_gemm_fp8_mx")
+    return out
+
+
+def conv3x3_fp8(x8, scale, pw, n_img, H, W, *, frames_per_scale=1, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0):
+    """3x3 conv, stride 1, pad 1, over the e4m3 output of groupnorm_fp8 (x8 (n_img, H*W, Cin) uint8, scale one per `frames_per_scale`
+    images) with fp8 weights (pack_conv3x3_fp8) -> (n_img, H*W, Cout) bf16; epilogue options as conv3x3."""
+    if x8.dtype != torch.uint8 or not x8.is_contiguous() or x8.shape[:2] != (n_img, H * W):
+        raise TypeError("conv3x3_fp8: x8 must be a contiguous (n_img, H*W, Cin) uint8 tensor")
+    cin = x8.shape[-1]
+    if pw.K != 9 * cin:
+        raise ValueError(f"conv3x3_fp8: weight K {pw.K} != 9*{cin}")
+    M = n_img * H * W
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x8), cin
+    d.amode, d.epi = AMODE_CONV3X3, EPI_LINEAR
+    d.H, d.Wd, d.Cin, d.Hout, d.Wout, d.stride, d.ups = H, W, cin, H, W, 1, 1
+    return _conv_fp8(d, x8, scale, frames_per_scale * H * W, pw, M, rowvec, H * W, res1, res2, alpha, beta).view(n_img, H * W, pw.N)
+
+
+def conv_t3_fp8(x8, scale, pw, T, S, *, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0):
+    """3x1x1 temporal conv, pad (1,0,0), over the e4m3 output of groupnorm_fp8(frames_per_group=T): x8 ((b t), S, Cin) uint8, scale (b,)."""
+    if x8.dtype != torch.uint8 or not x8.is_contiguous() or x8.shape[1] != S or x8.shape[0] % T:
+        raise TypeError("conv_t3_fp8: x8 must be a contiguous ((b t), S, Cin) uint8 tensor")
+    cin = x8.shape[-1]
+    if pw.K != 3 * cin:
+        raise ValueError("conv_t3_fp8: weight K mismatch")
+    M = x8.shape[0] * S
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x8), cin
+    d.amode, d.epi = AMODE_TEMPORAL3, EPI_LINEAR
+    d.Cin, d.T, d.S = cin, T, S
+    return _conv_fp8(d, x8, scale, T * S, pw, M, rowvec, S, res1, res2, alpha, beta).view(x8.shape[0], S, pw.N)
 
 
 def layernorm_quant_fp8(x, norm):
