@@ -43,6 +43,59 @@ def test_gemm_desc_layout_matches_header():
     assert names == [f[0] for f in _lib.VkGemmDesc._fields_], names
 
 
+def test_fp8_args_layout_matches_header():
+    """VkFp8Args (config 5 entry points): the ctypes mirror follows the C struct field for field."""
+    from vista_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "vista_hip.h")).read()
+    start = hdr.index("typedef struct VkFp8Args {") + len("typedef struct VkFp8Args {")
+    body = re.sub(r"/\*.*?\*/", "", hdr[start:hdr.index("} VkFp8Args;")], flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl.strip()).strip()
+        if decl:
+            names.append(decl.lstrip("*"))
+    assert names == [f[0] for f in _lib.VkFp8Args._fields_], names
+
+
+def test_fp8_conv_weight_packing_and_groupnorm_scale_bound_on_cpu():
+    """Host side of the fp8 ResBlock path (no launch). (1) pack_conv3x3_fp8 / pack_conv_t3_fp8: K order [Cout][Cin/64][tap][64] in
+    bytes, rows padded to 128, per-output-channel scales that reproduce the weights to e4m3 precision. (2) the scale rule of
+    vk_groupnorm_silu_fp8 (include/vista_hip.h): with y = a_c x + b_c the folded GroupNorm and max|x| of the image, (max_c |a_c| max|x| +
+    |b_c|) bounds |SiLU(y)| for every element -- checked against a brute-force maximum, with and without SiLU."""
+    from vista_amd import ops
+    g = torch.Generator().manual_seed(3)
+    cout, cin = 40, 128
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5
+    pw = ops.pack_conv3x3_fp8(w, torch.zeros(cout), device="cpu")
+    assert pw.K == 9 * cin and pw.Kp % 128 == 0 and pw.wt.dtype == torch.uint8 and pw.wt.shape[1] == pw.Kp
+    deq = pw.wt[:cout, :pw.K].view(torch.float8_e4m3fn).float() * pw.scale[:cout, None]
+    back = deq.view(cout, cin // 64, 9, 64).permute(0, 1, 3, 2).reshape(cout, cin, 3, 3)       # -> [Cout][Cin][ky][kx]
+    assert (back - w).abs().max() <= 2 ** -4 * w.abs().amax() * 1.01
+    assert torch.equal(pw.wt[:cout, pw.K:], torch.zeros(cout, pw.Kp - pw.K, dtype=torch.uint8)), "the K padding must be zero bytes"
+    wt3 = torch.randn(cout, 64, 3, 1, 1, generator=g)
+    pt = ops.pack_conv_t3_fp8(wt3, None, device="cpu")
+    deq = pt.wt[:cout, :pt.K].view(torch.float8_e4m3fn).float() * pt.scale[:cout, None]
+    assert pt.K == 192 and pt.Kp == 256 and (deq.view(cout, 1, 3, 64).permute(0, 1, 3, 2).reshape(cout, 64, 3) - wt3[:, :, :, 0, 0]).abs().max() <= 0.07 * wt3.abs().max()
+    with pytest.raises(ValueError):
+        ops.pack_conv3x3_fp8(torch.randn(8, 48, 3, 3), None, device="cpu")  # Cin % 64
+
+    n, S, C = 3, 50, 64
+    x = torch.randn(n, S, C, generator=g) * torch.tensor([0.3, 2.0, 9.0])[:, None, None] + 1.0
+    x[1, 7, 5] = 40.0                                                                           # an outlier sets max|x|
+    gamma, beta = 1 + 0.5 * torch.randn(C, generator=g), 0.4 * torch.randn(C, generator=g)
+    xg = x.view(n, S, 32, C // 32)
+    mean = xg.mean((1, 3), keepdim=True)
+    rstd = (xg.var((1, 3), unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    a = (gamma.view(1, 1, 32, -1) * rstd).expand(n, 1, 32, C // 32)
+    b = beta.view(1, 1, 32, -1) - mean * a
+    y = xg * a + b
+    xmax = x.abs().amax((1, 2))
+    bound = (a.abs() * xmax.view(n, 1, 1, 1) + b.abs()).amax((1, 2, 3))
+    assert (y.abs().amax((1, 2, 3)) <= bound * 1.0001).all()
+    assert (torch.nn.functional.silu(y).abs().amax((1, 2, 3)) <= torch.maximum(bound, torch.tensor(0.2785)) * 1.0001).all()
+    assert (bound <= 8 * y.abs().amax((1, 2, 3))).all(), "the bound should stay within a few octaves of the data"
+
+
 def test_schedules_guiders_scalings_match_reference_kats():
     from vista_amd.modules.diffusionmodules import denoiser_scaling, discretizer, guiders
     kat = json.load(open(os.path.join(GOLD, "kat.json")))
