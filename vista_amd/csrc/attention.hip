@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
     }
 
     const int nt = n_tiles;
-    const float psum_limit = fast_exp2(rescale_thr + 5.f);
+    const float psum_limit = fast_exp2(fminf(rescale_thr, 100.f) + 5.f);  // finite whatever the tuning value: an overflowed row sum (+inf) must fail the test
     dma_tile(0, 0);
     __syncthreads();
 
