@@ -1,0 +1,94 @@
+"""CPU restatements of two device-side algorithms whose correctness argument is not "the same arithmetic in another order":
+
+* the MAX-FREE fast path of the spatial attention kernel (vista_amd/csrc/attention.hip): exponentials taken against the existing
+  softmax base, the tile validated afterwards through its row sums, redone with a re-base only when they exceed the limit;
+* the per-lane (tap, slab) stepping of the fp8 implicit-GEMM loaders (vista_amd/csrc/gemm_fp8.hip): two (slab, tap) units per
+  128-byte K-step, each lane advancing its own unit by two per step.
+
+Both are emulated here in plain torch on small cases and compared with the closed forms (exact softmax attention; the
+[Cin/64][tap][64] K order of the packed weights). The GPU tests check the kernels themselves."""
+import math
+
+import pytest
+import torch
+
+
+def _attention_max_free(q, k, v, tile=64, thr=6.0):
+    """fp32 emulation of the kernel's tile loop for ONE query block (rows of q), keys streamed in tiles of `tile`.
+    Returns (out, number of tiles that took the slow path)."""
+    scale_log2 = q.shape[-1] ** -0.5 * math.log2(math.e)
+    n = q.shape[0]
+    m_run = torch.full((n,), -1e30)
+    l_run = torch.zeros(n)
+    o = torch.zeros(n, v.shape[-1])
+    limit = 2.0 ** (min(thr, 100.0) + 5.0)
+    slow_tiles = 0
+    for t0 in range(0, k.shape[0], tile):
+        s = q @ k[t0:t0 + tile].t()                                # scores of the tile
+
+        def rebase():
+            nonlocal m_run, l_run, o
+            mx = torch.maximum((s.amax(1) * scale_log2), torch.tensor(-1e30))
+            m_new = torch.maximum(m_run, mx)
+            alpha = torch.exp2(m_run - m_new)
+            m_run, l_run, o = m_new, l_run * alpha, o * alpha[:, None]
+        if t0 == 0:
+            rebase()
+        p = torch.exp2(s * scale_log2 - m_run[:, None]).to(torch.bfloat16).float()   # rounded like the MFMA operand
+        # the kernel tests every LANE's partial sum (32 of the 64 keys); testing per row halves is the same predicate here
+        halves = torch.stack([p[:, :tile // 2].sum(1), p[:, tile // 2:].sum(1)], 1)
+        if not bool((halves <= limit).all()):                       # wave-uniform in the kernel: any failing lane redoes the tile
+            slow_tiles += 1
+            rebase()
+            p = torch.exp2(s * scale_log2 - m_run[:, None]).to(torch.bfloat16).float()
+        l_run = l_run + p.sum(1)
+        o = o + p @ v[t0:t0 + tile].to(torch.bfloat16).float()
+    return o / l_run[:, None], slow_tiles
+
+
+@pytest.mark.parametrize("gain", [0.0, 3.0, 12.0, 60.0, 400.0])
+def test_attention_max_free_fast_path_equals_softmax(gain):
+    g = torch.Generator().manual_seed(int(gain) + 1)
+    S, d = 640, 64
+    q = torch.randn(32, d, generator=g)
+    k = torch.randn(S, d, generator=g)
+    v = torch.randn(S, d, generator=g)
+    if gain:
+        for j, row in enumerate(range(70, S, 97)):                 # late keys strongly aligned with single queries
+            k[row] = q[(5 * j + 3) % 32] * gain
+        k[:64] = -q[9] * gain                                       # query 9: first tile far below its later scores
+        k[S - 1] = q[9] * gain
+    q[11] = 0                                                       # uniform softmax row
+    out, slow = _attention_max_free(q, k, v)
+    ref = torch.softmax((q @ k.t()) * d ** -0.5, -1) @ v.to(torch.bfloat16).float()
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max() <= 2e-2 * ref.abs().max() + 1e-3
+    if gain == 0.0:
+        assert slow == 0, "Gaussian scores must never leave the fast path after tile 0"
+    if gain >= 60.0:
+        assert slow >= 1, "scores that overflow exp2 against the old base must be caught by the row-sum test"
+
+
+@pytest.mark.parametrize("taps,cin", [(9, 320), (9, 64), (9, 128), (3, 320), (3, 64), (3, 1280), (9, 960)])
+def test_fp8_conv_loader_unit_stepping_matches_k_order(taps, cin):
+    """Lane state of gemm_fp8.hip's implicit-GEMM loaders: chunk j (0..7) of a 128-byte K-step belongs to unit 2*kt + (j >> 2) of the
+    [Cin/64][tap][64] K order; the lane keeps (tap, channel base) and adds two units per step. Emulates the stepping for every
+    chunk and checks each staged 16-byte chunk against the closed form, including the empty second half of an odd last step."""
+    n_units = taps * (cin // 64)
+    ksteps = (n_units + 1) // 2
+    for j in range(8):
+        tap, cbase = j >> 2, 0                                     # initial lane state (tap_l = lsrc >> 2, cbase_l = 0)
+        for kt in range(ksteps):
+            inside = cbase < cin
+            unit = 2 * kt + (j >> 2)
+            assert inside == (unit < n_units)
+            if inside:
+                # K byte offset this chunk lands at vs the packed weight's K index of (slab, tap, channel)
+                k_index = kt * 128 + j * 16
+                slab, t = divmod(unit, taps)
+                assert (tap, cbase) == (t, slab * 64)
+                assert k_index == (slab * taps + t) * 64 + (j & 3) * 16
+            tap += 2
+            if tap >= taps:
+                tap -= taps
+                cbase += 64
