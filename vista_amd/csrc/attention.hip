@@ -2,8 +2,9 @@
 //
 // vk_attn_spatial_bf16 -- flash-style spatial self-attention (BasicTransformerBlock.attn1;
 //   vwm/modules/attention.py:370-407,514-518): per (image, head), N = H*W tokens, d = 64, no mask.
-//   Work decomposition: one workgroup = 256 (S >= 2048) or 128 query rows (8 / 4 waves x 32 rows) of one (image, head); KV is streamed
-//   in 64-key tiles through a 2-stage LDS ring (K tile [64 keys][64 d], V^T tile [64 d][64 keys], 8 KiB each).
+//   Work decomposition: one workgroup = 512 (S >= 4096: 8 waves x 64 rows, two 32-row query blocks per wave so that every K / V^T fragment
+//   read feeds two MFMAs), 256 (S >= 2048: 8 x 32) or 128 (4 x 32) query rows of one (image, head); KV is streamed in 64-key tiles
+//   through a 2-stage LDS ring (K tile [64 keys][64 d], V^T tile [64 d][64 keys], 8 KiB each).
 //   The score MFMA is issued swapped, S^T = K . Q^T, so a lane owns ONE query column and 32 of the tile's keys:
 //   the row max / row sum are lane-local plus a single lane^32 exchange, and the bf16 probabilities are already
 //   in MFMA B-operand position for O^T = V^T . P^T. The K tile's rows are stored PERMUTED (row bits [g1 g0 h e1 e0] hold
@@ -13,7 +14,8 @@
 //   LDS-DMA (global_load_lds_dwordx4; the row permutation and the bank swizzle live in the per-lane SOURCE address,
 //   keys past the sequence end read a zero word), 2-stage ring, one barrier per 64-key tile.
 //   LDS swizzle (both tiles, 128-B rows): 16-B chunk ^= (row>>1)&7 -> ds_read_b128 conflict-free.
-//   Occupancy: 117 VGPRs, 32 KiB LDS -> TWO workgroups (16 waves) per CU. What the loop costs is close to the SUM of its MFMA issue
+//   Occupancy: 117 VGPRs, 32 KiB LDS -> TWO workgroups (16 waves) per CU for the 32-row-per-wave forms; the 64-row form uses 200 VGPRs
+//   (one 8-wave workgroup per CU, 2 waves per SIMD) and is 4 % faster at S = 9216. What the loop costs is close to the SUM of its MFMA issue
 //   time (16 x 32 cycles per wave and tile) and its VALU issue time (~150 instructions, 33 of them v_exp at ~2.7x a plain VALU op):
 //   ablations with the softmax or 3/4 of the MFMAs removed, the per-instruction issue rates and three software-pipelined variants
 //   (32-key sub-steps with the next scores / this tile's exponentials / the previous PV interleaved in one wave, 3-stage ring) are in

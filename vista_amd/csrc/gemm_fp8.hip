@@ -13,9 +13,11 @@
 // the scale of (row r, block b) is byte op_sel of the scale VGPR of lane r + 32b. The fragment loader below therefore hands lane half
 // h the 16-B chunks (h, 2 + h) of each 64-byte K-slab: chunks (0,1) = block 0 and (2,3) = block 1 are 32 CONSECUTIVE k-bytes in memory.
 //
-// Two ways to scale the activations: per ROW (a_scale, applied to the accumulators after the K-loop: inputs quantised by
-// vk_quantize_rows_fp8 / vk_layernorm_quant_fp8) or per (row, 32-element block) in the MFMA itself (a_mx: the producer GEMM's epilogue
-// quantised its own output locally -- GEGLU with mx_out -- so no quantisation pass exists between the two FeedForward GEMMs).
+// Three ways to scale the activations: per ROW (a_scale, applied to the accumulators after the K-loop: inputs quantised by
+// vk_quantize_rows_fp8 / vk_layernorm_quant_fp8), per n consecutive rows (a_div: the per-image scales of vk_groupnorm_silu_fp8, for the
+// implicit-GEMM convolution loaders below -- a conv pixel only sums taps of its own image, so the scale factors out of the K-sum) or per
+// (row, 32-element block) in the MFMA itself (a_mx: the producer GEMM's epilogue quantised its own output locally -- GEGLU with mx_out --
+// so no quantisation pass exists between the two FeedForward GEMMs).
 #include "gemm_common.h"
 
 namespace {
