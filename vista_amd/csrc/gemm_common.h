@@ -25,6 +25,15 @@ __device__ __forceinline__ uint4 widen_pair(uint2 qa, uint2 qb) {
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
 
+// The inverse, for loads: the lower lane read the 8 contiguous bf16 of quad g (its own 4 and its partner's 4), the upper lane those of
+// quad g+1; two swaps hand every lane its own 4 values of both quads.
+__device__ __forceinline__ void unwiden_pair(const uint4& w, uint2& qa, uint2& qb) {
+    const auto rx = __builtin_amdgcn_permlane32_swap(w.x, w.z, false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(w.y, w.w, false, false);
+    qa = make_uint2(rx[0], ry[0]);
+    qb = make_uint2(rx[1], ry[1]);
+}
+
 // LayerNorm fold (VkGemmDesc.ln_*): (mean, rstd) of activation row m from the producer's partial sums, summed in slab order. The GEMM
 // kernel evaluates this ONCE per tile row at kernel start (the HBM latency of the slab reads hides behind the first tile's DMA) and
 // parks the pairs in LDS; the epilogues read them back with ds_read -- reading the slabs from the epilogue itself exposed ~2 us of
@@ -56,6 +65,11 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
         const uint16_t* __restrict__ res2 = (const uint16_t*)p.res2;
         // 16-byte stores need whole 16-column groups and 16-byte aligned rows (always true for the UNet's shapes)
         const bool wide = !OUT_F32 && (p.N % 16 == 0) && (p.ldc % 8 == 0) && (((size_t)p.out & 15) == 0);
+        // ... and so do 16-byte RESIDUAL loads (unwiden_pair): a lane's natural residual access is 8 bytes of a 640-byte-strided row, 20 of
+        // them per residual and wave tile, each touching 32 cache lines for 16 bytes apiece; pairs of quads read as one 16-byte load per
+        // lane halve the instructions and double the bytes used per line touched
+        const bool wide1 = res1 && (p.N % 16 == 0) && (p.ld_res1 % 8 == 0) && (((size_t)res1 & 15) == 0);
+        const bool wide2 = res2 && (p.N % 16 == 0) && (p.ld_res2 % 8 == 0) && (((size_t)res2 & 15) == 0);
 #pragma unroll
         for (int fj = 0; fj < FY; ++fj) {
             const int m = m0 + wm * MW + fj * 32 + l31;
@@ -68,6 +82,41 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
 #pragma unroll
             for (int fi = 0; fi < FX; ++fi) {
                 uint2 packed[4];
+                uint2 r1q[4], r2q[4];  // the residuals' quads of this fragment
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { r1q[g] = make_uint2(0, 0); r2q[g] = make_uint2(0, 0); }
+                if (res1) {
+                    if (wide1) {
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const int nb = n0 + wn * NW + fi * 32 + 16 * gp;
+                            const uint4 w = nb < p.N ? *(const uint4*)(res1 + (size_t)m * p.ld_res1 + nb + 8 * lh) : make_uint4(0, 0, 0, 0);
+                            unwiden_pair(w, r1q[2 * gp], r1q[2 * gp + 1]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = n0 + wn * NW + fi * 32 + 8 * g + 4 * lh;
+                            if (n < p.N) r1q[g] = *(const uint2*)(res1 + (size_t)m * p.ld_res1 + n);
+                        }
+                    }
+                }
+                if (res2) {
+                    if (wide2) {
+#pragma unroll
+                        for (int gp = 0; gp < 2; ++gp) {
+                            const int nb = n0 + wn * NW + fi * 32 + 16 * gp;
+                            const uint4 w = nb < p.N ? *(const uint4*)(res2 + (size_t)m * p.ld_res2 + nb + 8 * lh) : make_uint4(0, 0, 0, 0);
+                            unwiden_pair(w, r2q[2 * gp], r2q[2 * gp + 1]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = n0 + wn * NW + fi * 32 + 8 * g + 4 * lh;
+                            if (n < p.N) r2q[g] = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = n0 + wn * NW + fi * 32 + 8 * g + 4 * lh;
@@ -90,13 +139,13 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
                     if (res1) {
-                        const uint2 r = *(const uint2*)(res1 + (size_t)m * p.ld_res1 + n);
+                        const uint2 r = r1q[g];
                         v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
                     if (res2) {
-                        const uint2 r = *(const uint2*)(res2 + (size_t)m * p.ld_res2 + n);
+                        const uint2 r = r2q[g];
                         float t[4] = {bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y)};
                         if (rv2) {
                             const float4 b = *(const float4*)(rv2 + n);
