@@ -121,7 +121,7 @@ class ResBlock(TimestepBlock, Packable):
             pk["emb"] = ops.pack_linear(self.emb_layers[1].weight, self.emb_layers[1].bias, dev)
         if not isinstance(self.skip_connection, nn.Identity):
             pk["skip"] = ops.pack_linear(self.skip_connection.weight, self.skip_connection.bias, dev)
-        if FP8["conv"] and not self.full3d:
+        if FP8["conv"] and not self.full3d and self.emb_layers is not None:  # the UNet's ResBlocks only (the VAE decoder's time_stack has no embedding)
             pc8 = ops.pack_conv3x3_fp8 if self.dims == 2 else ops.pack_conv_t3_fp8
             pk["conv1_8"] = pc8(self.in_layers[2].weight, self.in_layers[2].bias, device=dev)
             pk["conv2_8"] = pc8(self.out_layers[3].weight, self.out_layers[3].bias, device=dev)
@@ -164,7 +164,7 @@ class ResBlock(TimestepBlock, Packable):
 
         def halo(t):
             return shard.halo_exchange(t) if (shard is not None and self.dims == 3) else (None, None)
-        if FP8["conv"] and shard is None and not self.full3d:
+        if FP8["conv"] and shard is None and not self.full3d and self.emb_layers is not None:
             # BASELINE config 5: both convolutions in fp8 e4m3. The GroupNorm+SiLU pass writes e4m3 with one scale per image (per clip for the
             # temporal norm) -- half the bytes it wrote before -- and the implicit-GEMM loaders stream those bytes; no quantisation pass.
             if "conv1_8" not in pk:  # the switch was flipped after the bf16 pack was built
