@@ -5,7 +5,10 @@
 * the per-lane (tap, slab) stepping of the fp8 implicit-GEMM loaders (vista_amd/csrc/gemm_fp8.hip): two (slab, tap) units per
   128-byte K-step, each lane advancing its own unit by two per step.
 
-Both are emulated here in plain torch on small cases and compared with the closed forms (exact softmax attention; the
+* the block-scale rule of the GEGLU epilogue's MX fp8 output (gemm_fp8.hip): frexp of max|h| / 448 gives the smallest power of two
+  that keeps the block inside e4m3's range.
+
+All are emulated here in plain torch on small cases and compared with the closed forms (exact softmax attention; the
 [Cin/64][tap][64] K order of the packed weights). The GPU tests check the kernels themselves."""
 import math
 
@@ -92,3 +95,21 @@ def test_fp8_conv_loader_unit_stepping_matches_k_order(taps, cin):
             if tap >= taps:
                 tap -= taps
                 cbase += 64
+
+
+def test_mx_block_scale_rule_is_the_tightest_power_of_two():
+    """GEGLU epilogue, MX fp8 output: per 32-column block `frexpf(amax / 448, &ex)` (amax / 448 = f * 2^ex, f in [0.5, 1)) and the
+    E8M0 byte ex + 127. For every positive amax: amax / 2^ex <= 448 (nothing saturates), amax / 2^(ex-1) > 448 (no smaller power of
+    two would do), the scaled values round to finite e4m3 codes, and the clamps keep the byte inside [0, 254] (255 is NaN in E8M0)."""
+    g = torch.Generator().manual_seed(0)
+    amax = torch.cat([torch.exp2(torch.rand(4000, generator=g) * 80 - 40), torch.tensor([448.0, 224.0, 1.0, 447.99, 448.01, 1e-38, 3e38])])
+    f, ex = torch.frexp(amax / 448.0)
+    assert ((f >= 0.5) & (f < 1.0)).all()
+    ex = ex.clamp(-127, 127)
+    two_e = torch.exp2(ex.float())
+    ok = ex > -127                                                   # (the clamp only bites below 2^-127 * 448)
+    assert (amax[ok] / two_e[ok] <= 448.0).all() and (amax[ok] / (two_e[ok] / 2) > 448.0 * (1 - 1e-6)).all()
+    codes = (amax[ok] / two_e[ok]).to(torch.float8_e4m3fn).float()
+    assert torch.isfinite(codes).all() and (codes >= 208).all() and (codes <= 448).all()
+    byte = ex + 127
+    assert (byte >= 0).all() and (byte <= 254).all()
