@@ -311,3 +311,74 @@ def test_gelu_logistic_quintic_formula():
     fin = x.abs() <= 1e4
     assert (got[fin] - ref[fin]).abs().max().item() <= 2.6e-5
     assert got[-2].item() == ref[-2].item() and got[-3].item() == 0.0   # +3e38 -> x, -3e38 -> -0
+
+
+def test_packable_cache_key_sees_replaced_parameters_and_inference_tensors():
+    """the pack cache must notice a REPLACED nn.Parameter (load_state_dict(assign=True), `m.weight = nn.Parameter()`),
+    whose old object would keep its version counter for ever, and must not trip over inference-mode tensors (no `_version`)."""
+    import torch.nn as nn
+    from vista_amd.modules.attention import Packable
+
+    class Stub(nn.Module, Packable):
+        _pack_device_types = ("cpu", "cuda")  # test-only: the product classes pack on the GPU only
+
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 4)
+            self.packs = 0
+
+        def _pack(self, dev):
+            self.packs += 1
+            return {"w": self.lin.weight.detach().clone()}
+
+    m = Stub()
+    pk0 = m.packed()
+    assert m.packed() is pk0 and m.packs == 1
+    # 1. in-place update: version counter
+    with torch.no_grad():
+        m.lin.weight.add_(1.0)
+    pk1 = m.packed()
+    assert pk1 is not pk0 and torch.equal(pk1["w"], m.lin.weight)
+    # 2. the Parameter OBJECT is replaced: the cached tensor's version never changes
+    m.lin.weight = nn.Parameter(torch.full((4, 4), 7.0))
+    pk2 = m.packed()
+    assert pk2 is not pk1 and float(pk2["w"][0, 0]) == 7.0
+    # 3. load_state_dict(assign=True) on a PARENT container replaces the Parameters without touching the child's load_state_dict
+    holder = nn.ModuleDict({"inner": m})
+    sd = {k: torch.full_like(v, 3.0) for k, v in holder.state_dict().items()}
+    holder.load_state_dict(sd, assign=True)
+    pk3 = m.packed()
+    assert pk3 is not pk2 and float(pk3["w"][0, 0]) == 3.0
+    assert m.packed() is pk3
+    # 4. inference-mode tensors have no version counter
+    with torch.inference_mode():
+        m2 = Stub()
+        m2.lin.weight = nn.Parameter(torch.ones(4, 4), requires_grad=False)
+    assert m2.lin.weight.is_inference()
+    assert m2.packed() is m2.packed()
+    # 5. a load through a VideoUNet drops every pack under it (post-hook), whatever the keys say
+    from vista_amd.modules.diffusionmodules.video_model import VideoUNet
+    from vista_amd.config import unet_kwargs
+    net = VideoUNet(**unet_kwargs(model_channels=64, channel_mult=[1], attention_resolutions=[1], num_res_blocks=1))
+    packables = [x for x in net.modules() if isinstance(x, Packable)]
+    for x in packables:
+        x._pk = {"stale": True}
+    net.load_state_dict(net.state_dict())
+    assert all(x._pk is None for x in packables)
+
+
+def test_config_fallback_equals_shipped_yaml_and_import_is_lazy():
+    """`import vista_amd.config` neither needs PyYAML nor the sibling configs/ directory."""
+    import vista_amd.config as cfg
+    assert cfg.load_config()["model"]["params"]["network_config"]["params"] == cfg._FALLBACK_UNET_KWARGS
+    assert cfg.VISTA_UNET_KWARGS == cfg._FALLBACK_UNET_KWARGS
+    saved, cfg._UNET_KWARGS = cfg._UNET_KWARGS, None
+    real = cfg.CONFIG_PATH
+    try:
+        cfg.CONFIG_PATH = "/nonexistent/vista.yaml"
+        cfg.load_config.__defaults__ = (cfg.CONFIG_PATH,)
+        assert cfg.unet_kwargs(64)["model_channels"] == 64 and cfg.unet_kwargs()["context_dim"] == 1024
+    finally:
+        cfg.CONFIG_PATH = real
+        cfg.load_config.__defaults__ = (real,)
+        cfg._UNET_KWARGS = saved

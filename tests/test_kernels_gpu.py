@@ -561,6 +561,31 @@ def test_linear_layernorm_fold(cfg, M, C, N):
         ops.linear(x, ops.pack_linear(w, b), ln=ops.rowstats(x))
 
 
+@pytest.mark.parametrize("ratio", [8.0, 60.0])
+@pytest.mark.parametrize("C", [320, 1280])
+def test_linear_layernorm_fold_large_mean_over_std(ratio, C):
+    """the fold takes the variance as E[x^2] - mean^2 from fp32 row sums; rows with |mean| >> std lose precision to
+    cancellation. Stated range: |mean| <= 60 std stays inside the kernel tolerance (fp32 sums over C <= 1280 columns resolve the
+    variance to ~1 %); the row sums come from BOTH producers of the product path (the read-only pass and a GEMM epilogue)."""
+    ops = _ops()
+    M, N = 700, 640
+    g = torch.Generator(device="cpu").manual_seed(5)
+    sign = (torch.randint(0, 2, (M, 1), generator=g) * 2 - 1).float()
+    x = (torch.randn(M, C, generator=g) + ratio * sign).to(BF16).cuda()   # per-row mean = +-ratio, std ~1 (bf16 grid: 0.25-0.5 at 60)
+    w = rnd(N, C, scale=C ** -0.5, seed=1)
+    b = rnd(N, seed=2).float()
+    norm = _Norm(C, 11)
+    pw = ops.pack_linear(w, b, ln=norm)
+    ref = _ln_ref(x, norm.weight, norm.bias) @ w.float().t() + b
+    out = ops.linear(x, pw, ln=ops.rowstats(x))
+    close(out, ref, f"ln-fold, mean/std {ratio}, C {C}, rowstats pass")
+    # the same rows produced by a GEMM epilogue (identity weight): its (sum, sum of squares) slabs feed the consumer
+    eye = ops.pack_linear(torch.eye(C), None)
+    x2, st = ops.linear(x, eye, emit_stats=True)
+    assert torch.equal(x2, x)
+    close(ops.linear(x2, pw, ln=st), ref, f"ln-fold, mean/std {ratio}, C {C}, producer-epilogue stats")
+
+
 def test_layernorm_fold_chain_producer_stats():
     """producer GEMM (emits row sums of its output) -> consumer GEMMs with the folded norm: LINEAR (q|k), TRANS (v^T), GEGLU."""
     ops = _ops()
@@ -683,3 +708,14 @@ def test_packed_weights_follow_parameter_versions():
     from vista_amd.modules.attention import invalidate_packed
     invalidate_packed(holder)
     assert ff.packed() is not pk2
+    # a REPLACED Parameter object (load_state_dict(assign=True), re-assignment): the old object's version would never change
+    pk3 = ff.packed()
+    ff.net[2].weight = nn.Parameter(ff.net[2].weight.detach() * 3.0)
+    assert ff.packed() is not pk3
+    pk4 = ff.packed()
+    holder.load_state_dict({k: v.clone() for k, v in holder.state_dict().items()}, assign=True)
+    assert ff.packed() is not pk4
+    y2 = ff(x)
+    ref2 = (lambda h: (h[:, :256] * F.gelu(h[:, 256:])) @ (3.0 * sd["inner.0.net.2.weight"].float()).t() + sd["inner.0.net.2.bias"])(
+        x.float() @ sd["inner.0.net.0.proj.weight"].float().t() + sd["inner.0.net.0.proj.bias"])
+    close(y2, ref2.to(BF16).float(), "FeedForward after Parameter replacement", rtol=3e-2, arel=3e-2)

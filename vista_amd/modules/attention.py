@@ -31,30 +31,56 @@ def default(val, d):
 
 
 class Packable:
-    """Lazy bf16 weight packing (ops.pack_*). The pack is keyed on the device, dtype and in-place version counters of the
+    """Lazy bf16 weight packing (ops.pack_*). The pack is keyed on the device, dtype, identity and in-place version counters of the
     parameters it was built from, so it is rebuilt after `.cuda()`, after ANY load_state_dict (also one issued on a parent
-    container, which never reaches the children's own load_state_dict) and after in-place updates of the Parameters
-    (`p.copy_()`, `p.mul_()` under no_grad). Writes through `p.data` (the reference's LitEma.copy_to, vwm/modules/ema.py) carry
-    their own version counter by PyTorch's design and are invisible here: call `invalidate_packed(model)` after them."""
+    container, which never reaches the children's own load_state_dict; also `assign=True`, which REPLACES the Parameter objects),
+    after `module.weight = nn.Parameter(...)` and after in-place updates of the Parameters (`p.copy_()`, `p.mul_()` under no_grad).
+    Replacement is detected through the owning modules' `_parameters` slots: every call checks that each slot still holds the very
+    object the pack was built from (a dict lookup per parameter; re-walking `parameters()` would cost ~10 us x 600 packs per step).
+    Writes through `p.data` (the reference's LitEma.copy_to, vwm/modules/ema.py) carry their own version counter by PyTorch's design
+    and are invisible here: call `invalidate_packed(model)` after them."""
     _pk = None
     _pk_key = None
     _pk_params = None
+    _pack_device_types = ("cuda",)  # (the CPU tests of the cache-key logic widen this on a stub class; product classes never do)
 
     def _pack_params(self):
         """Parameters the pack depends on (default: every parameter under this module)."""
         return list(self.parameters())
 
+    def _resolve_pack_params(self):
+        """[(owner `_parameters` dict or None, name, tensor)] for every tensor of _pack_params(). The owner slot is what lets packed()
+        notice a REPLACED Parameter (the cached tensor itself would keep its old version counter for ever)."""
+        ps = self._pack_params()
+        where = {}
+        for m in self.modules():
+            for n, q in m._parameters.items():
+                if q is not None:
+                    where.setdefault(id(q), (m._parameters, n))
+        slots = [(*where.get(id(q), (None, None)), q) for q in ps]
+        object.__setattr__(self, "_pk_params", slots)  # plain attribute: nn.Module.__setattr__ would try to register it
+        return slots
+
+    @staticmethod
+    def _param_version(p):
+        return 0 if p.is_inference() else p._version  # inference tensors (a model moved under torch.inference_mode()) have no counter
+
     def packed(self):
-        ps = self._pk_params
-        if ps is None:
-            ps = self._pack_params()
-            object.__setattr__(self, "_pk_params", ps)  # plain attribute: nn.Module.__setattr__ would try to register it
-        p0 = ps[0]
+        slots = self._pk_params
+        if slots is None:
+            slots = self._resolve_pack_params()
+        else:
+            for d, n, q in slots:
+                if d is not None and d.get(n) is not q:  # the Parameter object was replaced (assign=True load, re-assignment, parametrize)
+                    slots = self._resolve_pack_params()
+                    self._pk = None
+                    break
+        p0 = slots[0][2]
         dev = p0.device
-        if dev.type != "cuda":
+        if dev.type not in self._pack_device_types:
             raise ops._lib.VistaHipError(f"{self.__class__.__name__}: parameters are on {dev}; move the model to the MI355X "
                                          "(.cuda()) -- vista_amd has no CPU path")
-        key = (dev, p0.dtype, *[p._version for p in ps])
+        key = (dev, p0.dtype, *[(id(q), self._param_version(q)) for _, _, q in slots])
         if self._pk is None or self._pk_key != key:
             with torch.no_grad():
                 self._pk = self._pack(dev)
@@ -63,7 +89,11 @@ class Packable:
 
     def invalidate_packed(self):
         self._pk = None
-        object.__setattr__(self, "_pk_params", None)  # a replaced nn.Parameter object is picked up on the next pack
+        object.__setattr__(self, "_pk_params", None)  # the parameter list is re-resolved on the next pack
+
+
+def _invalidate_after_load(module, incompatible_keys):
+    invalidate_packed(module)
 
 
 def invalidate_packed(module):
@@ -99,8 +129,9 @@ class FeedForward(nn.Module, Packable):
             zero_module(self.net[-1])
 
     def _pack(self, dev):
-        pk = {"in": ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, dev),
-              "out": ops.pack_linear(self.net[2].weight, self.net[2].bias, dev)}
+        # "in" (the UNFOLDED GEGLU weight) is packed on first use by forward(): the UNet path only runs forward_folded, whose LN-folded
+        # copy belongs to the owning block -- packing both would keep ~0.6 GB of dead bf16 weights on the device for the 1.65 B network
+        pk = {"out": ops.pack_linear(self.net[2].weight, self.net[2].bias, dev)}
         if FP8["feedforward"]:
             pk["in8"] = ops.pack_geglu_fp8(self.net[0].proj.weight, self.net[0].proj.bias, dev)
             pk["out8"] = ops.pack_linear_fp8(self.net[2].weight, self.net[2].bias, dev)
@@ -115,6 +146,8 @@ class FeedForward(nn.Module, Packable):
         by the fp8 experiment and by callers that already hold a normalised input)."""
         pk = self.packed()
         if not FP8["feedforward"]:
+            if "in" not in pk:  # lives in the pack dict, so it is dropped with it whenever the parameters change
+                pk["in"] = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight.device)
             return ops.linear(ops.linear(y, pk["in"]), pk["out"], **epilogue)
         if "in8" not in pk:  # the switch was flipped after the bf16 pack was built
             self.invalidate_packed()

@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from ... import ops
 from ...util import default, repeat_as_img_seq
-from ..attention import Packable
+from ..attention import Packable, _invalidate_after_load as _drop_packs_after_load
 from ..video_attention import SpatialVideoTransformer
 from .openaimodel import Downsample, ResBlock, Timestep, TimestepEmbedSequential, Upsample  # noqa: F401
 from .util import AlphaBlender, SiLU, conv_nd, linear, mlp_f32, normalization, timestep_embedding, zero_module
@@ -239,6 +239,8 @@ class VideoUNet(nn.Module, Packable):
         # (64 launches of 1..50-row GEMMs with K = 3456 per forward -> 2; they were 1.5 % of a single-GPU step and 7 % of an 8-GPU rank's).
         from ..attention import BasicTransformerBlock
         from ..video_attention import VideoTransformerBlock
+        # belt and braces next to the packs' own (identity, version) keys: a load through THIS module drops every pack under it
+        self.register_load_state_dict_post_hook(_drop_packs_after_load)
         self._ctx_layers = {"ctx_s": [], "ctx_t": []}
         offs = {"ctx_s": 0, "ctx_t": 0}
         for m in self.modules():
@@ -272,6 +274,8 @@ class VideoUNet(nn.Module, Packable):
         emb_b = torch.cat([m.emb_layers[1].bias.detach().float() for m in self._emb_blocks], 0)
         ctx = {}
         for key, layers in self._ctx_layers.items():
+            if not layers:  # disable_temporal_crossattention=True: no temporal cross-attention layers to batch
+                continue
             maps = [a.context_map() for a in layers]
             ctx[key] = ops.pack_linear(torch.cat([w for w, _ in maps], 0), torch.cat([b for _, b in maps], 0), dev)
         return {"emb_cat": ops.pack_linear(emb_w, emb_b, dev), **ctx,
@@ -337,8 +341,8 @@ class VideoUNet(nn.Module, Packable):
 
         clip_ctx = (ctx if full is None else full["ctx"]).view(n_img // T, T, -1)[:, 0]  # context[::T]: first frame of every clip
         self._emb_tls.table = {"emb": ops.linear(emb_silu, pk["emb_cat"], out_f32=True),   # all emb_layers projections of this forward
-                               "ctx_s": ops.linear(ctx, pk["ctx_s"], out_f32=True),          # all spatial cross-attention context vectors
-                               "ctx_t": ops.linear(clip_ctx, pk["ctx_t"], out_f32=True)}     # all temporal ones (one per clip)
+                               "ctx_s": ops.linear(ctx, pk["ctx_s"], out_f32=True) if "ctx_s" in pk else None,        # all spatial cross-attention context vectors
+                               "ctx_t": ops.linear(clip_ctx, pk["ctx_t"], out_f32=True) if "ctx_t" in pk else None}   # all temporal ones (one per clip)
         try:
             hs = []
             h = tokens

@@ -161,16 +161,22 @@ TILE_CFG = 0  # 0 = auto; tests force 1/2/3/4 to cover every block-tile variant
 
 
 SPLITK_WS_BYTES = int(os.environ.get("VISTA_SPLITK_WS_MB", "160")) << 20  # fp32 split-K workspace per (device, stream) (0 disables split-K)
-_SPLITK_WS = {}
+class _SplitKTLS(threading.local):
+    def __init__(self):
+        self.ws = {}
+
+
+_SPLITK_WS = _SplitKTLS()
 
 
 def _splitk_workspace(stream):
-    """One workspace per (device, stream, host thread): launches on one stream are ordered, so they may share it; GEMMs in flight on
-    different streams must not (include/vista_hip.h, VkGemmDesc.splitk_ws)."""
-    key = (torch._C._cuda_getDevice(), stream.value, threading.get_ident())  # thread ranks (tests) share a stream but enqueue concurrently
-    ws = _SPLITK_WS.get(key)
+    """One workspace per (device, stream) of each host thread: launches on one stream are ordered, so they may share it; GEMMs in flight on
+    different streams must not (include/vista_hip.h, VkGemmDesc.splitk_ws), and thread ranks (tests) share a stream but enqueue
+    concurrently. Held in thread-local storage, so a worker thread's buffers are released when the thread exits."""
+    key = (torch._C._cuda_getDevice(), stream.value)
+    ws = _SPLITK_WS.ws.get(key)
     if ws is None:
-        ws = _SPLITK_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{key[0]}")
+        ws = _SPLITK_WS.ws[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{key[0]}")
     return ws
 
 
