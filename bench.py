@@ -124,9 +124,12 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-def plumbing_only(args, world, rank, dist, backend):
-    """Launch / rendezvous / partition check without touching a GPU (CPU test of the N > 1 launch path): builds both shard layouts,
-    round-trips a tensor through the frame<->pixel all-to-alls, the halo exchange and the statistics all-reduce on the host."""
+def plumbing_only(args, world, rank, dist, backend, device="cpu"):
+    """Launch / rendezvous / partition check with no model work: builds both shard layouts and runs FrameShard.selfcheck on each
+    (every collective signature of a sharded step -- unequal-split all_to_all_single at the four UNet levels, zero-length halo splits,
+    the 512-byte statistics all-reduce, padded all_gather lists -- with value checks). On the host over gloo (CPU test of the N > 1 launch
+    path) or, where GPUs are visible, on device tensors over RCCL: `bench.py --gpus N --plumbing-only` is the first thing to run on a
+    multi-GPU box."""
     from vista_amd.parallel import DistComm, make_shard
     T = args.frames
 
@@ -137,20 +140,13 @@ def plumbing_only(args, world, rank, dist, backend):
     for mode in ("hybrid", "frames"):
         sh = make_shard(T, world, rank, mode=mode, make_group=make_group)
         layouts[mode] = {"t_counts": sh.t_counts, "cfg_half": sh.cfg_half}
-        if sh.P > 1:
-            x = torch.arange(sh.B * sh.t_local * 12 * 4, dtype=torch.float32).view(sh.B * sh.t_local, 12, 4) + 1000 * rank
-            back = sh.to_frames(sh.to_pixels(x), 12)
-            assert torch.equal(back, x), "frame->pixel->frame all-to-all round trip"
-            sh.halo_exchange(x)
-        s = torch.ones(4)
-        sh.all_reduce_sum(s)
-        assert float(s[0]) == sh.P
-    t = torch.tensor([float(rank)], dtype=torch.float64)
+        sh.selfcheck(device)
+    t = torch.tensor([float(rank)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert int(t.item()) == world - 1
     if rank == 0:
         print(json.dumps({"metric": METRIC, "value": None, "unit": "steps/s", "n_gpus": world, "plumbing_only": True, "backend": backend,
-                          "layouts": layouts}), flush=True)
+                          "device": str(device), "layouts": layouts}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -229,7 +225,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.plumbing_only:
+        if args.plumbing_only and not (torch.cuda.is_available() and backend == "nccl"):
             dist.init_process_group("gloo")
             return plumbing_only(args, world, rank, dist, "gloo")
         torch.cuda.set_device(local_rank)
@@ -237,6 +233,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        if args.plumbing_only:
+            return plumbing_only(args, world, rank, dist, backend, device=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     if args.fp8_ff or args.fp8:
@@ -262,6 +260,14 @@ def main():
         other = "frames" if args.shard == "hybrid" else "hybrid"
         if not args.no_extras and world % 2 == 0:  # odd worlds have one layout only
             shards[other] = make_shard(T, world, rank, mode=other, make_group=make_group)
+        # Plumbing pass BEFORE any model work: every collective signature of the sharded step on tiny device tensors, synchronised one by
+        # one, so that a transport problem on a box this code has never seen is reported by name within seconds (vista_amd/parallel.py).
+        for key, sh in shards.items():
+            try:
+                sh.selfcheck(torch.device("cuda", local_rank))
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench rank {rank}] multi-GPU plumbing check FAILED for layout '{key}': {e}", file=sys.stderr, flush=True)
+                raise
     net = build_model(args.model_channels)
     w = synth.window_inputs(T=T, H=H, W=W, seed=0)
     cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731

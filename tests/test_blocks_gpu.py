@@ -7,6 +7,11 @@ one block has 4-25 bf16 roundings, so its floor is 2-6e-3 and the bound is tight
 (bf16 storage / fp32 accumulation / bf16-rounded weights vs fp32):
     ResBlock family, Downsample, Upsample, out conv :  rel-L2 <= 5e-3, max|err| <= 2e-2 * max|ref|
     SpatialVideoTransformer (two transformer blocks, ~25 stored bf16 tensors, bf16 softmax probabilities) : rel-L2 <= 8e-3, max <= 3e-2
+BASELINE config 5 (fp8 e4m3): the SAME blocks at the SAME shapes with the config's fp8 switches on, against the SAME
+fp32 oracle output (computed once per block). Re-stated tolerances, fp8 storage of GEMM operands with 3 mantissa bits
+(2^-4 = 6.3e-2 relative per element, averaged down by the K-sum) on residual branches:
+    ResBlock family with its four convolutions in fp8            :  rel-L2 <= 4e-2, max|err| <= 1.5e-1 * max|ref|
+    SpatialVideoTransformer with fp8 FeedForwards (+ attention / projections when those switches exist) : rel-L2 <= 4e-2, max <= 1.5e-1
 Inputs are bf16-representable; weights are the seeded non-zero init of vista_amd.synth (every zero-init tensor re-randomised).
 One window = 25 frames of ONE clip (b = 1): the CFG-doubled batch of the bench is two independent copies of this.
 Measured values are appended to gpurun_out/block_parity.json when that directory exists."""
@@ -45,6 +50,24 @@ def _seed(mod, prefix, seed):
     sd = synth.seeded_state_dict(shapes, seed)
     mod.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items()}, strict=True)
     return sd
+
+
+def _fp8(keys):
+    """Context manager: BASELINE config 5 switches `keys` on for the duration (whatever subset of them this build knows)."""
+    import contextlib
+    from vista_amd.modules import attention
+
+    @contextlib.contextmanager
+    def cm():
+        saved = dict(attention.FP8)
+        for k in keys:
+            if k in attention.FP8:
+                attention.FP8[k] = True
+        try:
+            yield
+        finally:
+            attention.FP8.update(saved)
+    return cm()
 
 
 def _report(name, out, ref, rl_tol, mx_tol, t_ref):
@@ -96,6 +119,12 @@ def test_video_resblock_at_baseline_shape(name, cin, cout, H, W):
     with torch.no_grad():
         out = blk(toks if len(toks) == 2 else toks[0], emb_silu, T, H, W)
     _report("VideoResBlock " + name, _nchw(out, T, H, W), ref, 5e-3, 2e-2, t_ref)
+    with torch.no_grad(), _fp8(["conv"]):  # BASELINE config 5: the block's four convolutions on e4m3 GroupNorm output
+        out8 = blk(toks if len(toks) == 2 else toks[0], emb_silu, T, H, W)
+    assert not torch.equal(out8, out), "the fp8 switch did not change the path"
+    _report("[fp8 conv] VideoResBlock " + name, _nchw(out8, T, H, W), ref, 4e-2, 1.5e-1, 0.0)
+    with torch.no_grad():
+        assert torch.equal(blk(toks if len(toks) == 2 else toks[0], emb_silu, T, H, W), out), "switching fp8 off restores the bf16 path bit for bit"
 
 
 TRANSFORMERS = [("L0 C=320 S=9216", 320, 72, 128), ("L1 C=640 S=2304", 640, 36, 64), ("L2 C=1280 S=576", 1280, 18, 32),
@@ -125,6 +154,16 @@ def test_spatial_video_transformer_at_baseline_shape(name, C, H, W):
     with torch.no_grad():
         out = blk(_tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W)
     _report("SpatialVideoTransformer " + name, _nchw(out, T, H, W), ref, 8e-3, 3e-2, t_ref)
+    for keys in (["feedforward"], ["feedforward", "attention", "proj"]):  # BASELINE config 5: FeedForwards, then everything the config names
+        from vista_amd.modules import attention
+        if not all(k in attention.FP8 for k in keys):
+            continue
+        with torch.no_grad(), _fp8(keys):
+            out8 = blk(_tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W)
+        assert not torch.equal(out8, out), "the fp8 switch did not change the path"
+        _report(f"[fp8 {'+'.join(keys)}] SpatialVideoTransformer " + name, _nchw(out8, T, H, W), ref, 4e-2, 1.5e-1, 0.0)
+    with torch.no_grad():
+        assert torch.equal(blk(_tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W), out)
 
 
 def test_downsample_upsample_outconv_at_baseline_shape():

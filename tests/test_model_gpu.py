@@ -205,29 +205,50 @@ def test_product_path_refuses_cpu():
             cond_mask=torch.zeros(2), num_frames=2)
 
 
+def oracle_50_step():
+    """(window inputs, the CPU oracle's 50-step result) of the 64-channel network at T=5, latent 16x32, VanillaCFG 2.5 -- ~1 min on the host,
+    so it is computed once per box (per-process dict + a file under the temp dir) and shared by the bf16 and fp8 tests."""
+    import tempfile
+    from oracle import vista_oracle as O
+    from vista_amd import synth
+    if "o50" in _CACHE:
+        return _CACHE["o50"]
+    net, shapes = tiny_unet()
+    sd = synth.seeded_state_dict(shapes, 0)
+    T, H, W, steps = 5, 16, 32, 50
+    w = synth.window_inputs(T=T, H=H, W=W, seed=31, n_cond=1, trajectory=TRAJ)
+    path = os.path.join(tempfile.gettempdir(), f"vista_oracle50_{synth.shapes_digest(shapes)[:12]}.pt")
+    if os.path.exists(path):
+        want = torch.load(path)
+    else:
+        with torch.no_grad():
+            want = O.euler_edm_sample(lambda a, s, c, m: O.denoiser_forward(sd, a, s, c, m, T), w["noise"], w["c"], w["uc"], w["cond_frame"],
+                                      w["cond_mask"], steps, scale=2.5)
+        torch.save(want, path)
+    _CACHE["o50"] = (w, want, T, steps)
+    return _CACHE["o50"]
+
+
+def run_50_step(net, w, T, steps):
+    from vista_amd.modules.diffusionmodules.denoiser import Denoiser
+    from vista_amd.modules.diffusionmodules.sampling import FusedDenoiser
+    from vista_amd.modules.diffusionmodules.wrappers import OpenAIWrapper
+    den = Denoiser(scaling_config={"target": "vwm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
+    s = _sampler({"target": "vwm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 2.5}}, steps=steps)
+    return s(FusedDenoiser(den, OpenAIWrapper(net)), w["noise"].clone().cuda(), cond=cu(w["c"]), uc=cu(w["uc"]),
+             cond_frame=w["cond_frame"].cuda(), cond_mask=w["cond_mask"].cuda()).cpu()
+
+
 def test_sampler_full_50_step_schedule_vs_oracle():
     """The WHOLE 50-step EDM schedule end to end (VERDICT r1 missing #6; the longest chain before was 10 steps): 64-channel network,
     T=5, latent 16x32, VanillaCFG 2.5, fused path, against the CPU oracle's 50-step run (computed here, ~1 min on the host).
     Each step is a contraction towards the denoised estimate (x <- x + (sigma_next/sigma - 1)(x - D(x))), so per-step bf16 noise does
     not grow without bound (measured 8.2e-3, below one forward's 1.3e-2); stated tolerance rel-L2 <= 2.5e-2, measured value appended to gpurun_out/parity_50step.json."""
     import json
-    from oracle import vista_oracle as O
-    from vista_amd import synth
-    from vista_amd.modules.diffusionmodules.denoiser import Denoiser
-    from vista_amd.modules.diffusionmodules.sampling import FusedDenoiser
-    from vista_amd.modules.diffusionmodules.wrappers import OpenAIWrapper
-    net, shapes = tiny_unet()
-    sd = synth.seeded_state_dict(shapes, 0)
-    T, H, W, steps = 5, 16, 32, 50
-    w = synth.window_inputs(T=T, H=H, W=W, seed=31, n_cond=1, trajectory=TRAJ)
-    with torch.no_grad():
-        want = O.euler_edm_sample(lambda a, s, c, m: O.denoiser_forward(sd, a, s, c, m, T), w["noise"], w["c"], w["uc"], w["cond_frame"],
-                                  w["cond_mask"], steps, scale=2.5)
-    den = Denoiser(scaling_config={"target": "vwm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
-    cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
-    s = _sampler({"target": "vwm.modules.diffusionmodules.guiders.VanillaCFG", "params": {"scale": 2.5}}, steps=steps)
-    got = s(FusedDenoiser(den, OpenAIWrapper(net)), w["noise"].clone().cuda(), cond=cu(w["c"]), uc=cu(w["uc"]),
-            cond_frame=w["cond_frame"].cuda(), cond_mask=w["cond_mask"].cuda()).cpu()
+    net, _ = tiny_unet()
+    w, want, T, steps = oracle_50_step()
+    got = run_50_step(net, w, T, steps)
     r = rel_l2(got, want)
     print(f"[parity] 50-step CFG EulerEDM (tiny net, T=5, 16x32) vs oracle: rel-L2 {r:.4e}")
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

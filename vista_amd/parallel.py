@@ -55,51 +55,83 @@ def make_shard(T, world, rank, mode="hybrid", make_group=None):
     make_group(list_of_ranks) -> communicator for that subgroup (must be called collectively, same order on all ranks)."""
     if world == 1:
         return None
+    def named(comm, name):
+        if comm is not None and hasattr(comm, "name"):
+            comm.name = name
+        return comm
     if mode == "frames" or world % 2:
-        return FrameShard(T, make_group(list(range(world))), B=2)
+        return FrameShard(T, named(make_group(list(range(world))), f"frames[0..{world - 1}]"), B=2)
     half = world // 2
-    groups = [make_group(list(range(h * half, (h + 1) * half))) if half > 1 else None for h in range(2)]
-    pairs = [make_group([i, i + half]) for i in range(half)]
+    groups = [named(make_group(list(range(h * half, (h + 1) * half))), f"cfg-half-{h}[{h * half}..{(h + 1) * half - 1}]") if half > 1 else None
+              for h in range(2)]
+    pairs = [named(make_group([i, i + half]), f"cfg-pair[{i},{i + half}]") for i in range(half)]
     h, i = rank // half, rank % half
     comm = groups[h] if half > 1 else SelfComm()
     return FrameShard(T, comm, B=1, cfg_pair=pairs[i], cfg_half=h)
 
 
+class CollectiveError(RuntimeError):
+    """A collective of the sharded step failed: names the collective, the group and the split lists (first contact with RCCL happens on
+    the driver's multi-GPU box, where the only diagnostics are what the process prints)."""
+
+
 class DistComm:
     """torch.distributed transport. With the gloo backend (CPU tests, and the single-GPU dry run of bench.py's multi-rank
-    path) device tensors are staged through host memory; with "nccl" (= RCCL) they go GPU-to-GPU over xGMI."""
+    path) device tensors are staged through host memory; with "nccl" (= RCCL) they go GPU-to-GPU over xGMI.
+    Every collective signature the nccl path uses is one of the three methods below (all_to_all_single with per-rank split lists that
+    may hold zeros, all_reduce(SUM), all_gather of equally padded tensors) and is exercised over gloo by tests/test_parallel_cpu.py."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, name="world"):
         import torch.distributed as dist
-        self.dist, self.group = dist, group
+        self.dist, self.group, self.name = dist, group, name
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)  # rank WITHIN the group
-        self.host_staged = dist.get_backend(group) == "gloo"
+        self.backend = dist.get_backend(group)
+        self.host_staged = self.backend == "gloo"
+
+    def _fail(self, what, e, **info):
+        detail = ", ".join(f"{k}={v}" for k, v in info.items())
+        raise CollectiveError(f"[global rank {self.dist.get_rank()}] {what} on group '{self.name}' (backend {self.backend}, "
+                              f"group rank {self.rank}/{self.world}) failed: {detail}: {type(e).__name__}: {e}") from e
 
     def all_to_all(self, recv, send, out_splits, in_splits):
-        if self.host_staged and recv.is_cuda:
-            r = torch.empty(recv.shape, dtype=recv.dtype)
-            self.dist.all_to_all_single(r, send.cpu(), out_splits, in_splits, group=self.group)
-            recv.copy_(r)
-            return
-        self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+        if len(out_splits) != self.world or len(in_splits) != self.world or sum(out_splits) != recv.numel() or sum(in_splits) != send.numel():
+            raise CollectiveError(f"all_to_all_single on group '{self.name}': split lists do not match the buffers: out_splits {out_splits} "
+                                  f"(recv {recv.numel()}), in_splits {in_splits} (send {send.numel()}), group size {self.world}")
+        try:
+            if self.host_staged and recv.is_cuda:
+                r = torch.empty(recv.shape, dtype=recv.dtype)
+                self.dist.all_to_all_single(r, send.cpu(), out_splits, in_splits, group=self.group)
+                recv.copy_(r)
+                return
+            self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+        except CollectiveError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            self._fail("all_to_all_single", e, dtype=recv.dtype, out_splits=out_splits, in_splits=in_splits, device=recv.device)
 
     def all_reduce_sum(self, t):
-        if self.host_staged and t.is_cuda:
-            c = t.cpu()
-            self.dist.all_reduce(c, group=self.group)
-            t.copy_(c)
-            return
-        self.dist.all_reduce(t, group=self.group)
+        try:
+            if self.host_staged and t.is_cuda:
+                c = t.cpu()
+                self.dist.all_reduce(c, group=self.group)
+                t.copy_(c)
+                return
+            self.dist.all_reduce(t, group=self.group)
+        except Exception as e:  # noqa: BLE001
+            self._fail("all_reduce(SUM)", e, dtype=t.dtype, numel=t.numel(), device=t.device)
 
     def all_gather_list(self, t, counts):
         mx = max(counts)  # pad to equal sizes: uneven all_gather is not portable across backends
         dev = t.device
-        src = t.cpu() if (self.host_staged and t.is_cuda) else t
-        pad = torch.zeros((mx,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-        pad[:src.shape[0]] = src
-        outs = [torch.empty_like(pad) for _ in counts]
-        self.dist.all_gather(outs, pad, group=self.group)
-        return [o[:c].to(dev) for o, c in zip(outs, counts)]
+        try:
+            src = t.cpu() if (self.host_staged and t.is_cuda) else t
+            pad = torch.zeros((mx,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+            pad[:src.shape[0]] = src
+            outs = [torch.empty_like(pad) for _ in counts]
+            self.dist.all_gather(outs, pad, group=self.group)
+            return [o[:c].to(dev) for o, c in zip(outs, counts)]
+        except Exception as e:  # noqa: BLE001
+            self._fail("all_gather (padded list)", e, dtype=t.dtype, counts=counts, shape=tuple(t.shape), device=dev)
 
 
 class ThreadGroups:
@@ -239,6 +271,79 @@ class FrameShard:
         self._plans[key] = plan
         return plan
 
+    def exchange_splits(self, S, C, rank=None):
+        """Element counts per peer of the three all_to_all_single calls of a block pair, for `rank` (default: this rank):
+        {"to_pixels": (in_splits, out_splits), "to_frames": (...), "halo": (...)}. Pure function of (T, P, B, S, C, rank): the CPU tests check
+        that every rank's out_splits[q] equals rank q's in_splits[r] for all world sizes and all four UNet levels."""
+        r = self.rank if rank is None else rank
+        B, P = self.B, self.P
+        sc = self.pixel_counts(S)
+        t_r, s_r = self.t_counts[r], sc[r]
+        fs = B * S * C
+        halo_in = [fs if abs(q - r) == 1 else 0 for q in range(P)]  # one boundary frame to each existing neighbour, nothing to the others
+        return {"to_pixels": ([B * t_r * sc[q] * C for q in range(P)], [B * self.t_counts[q] * s_r * C for q in range(P)]),
+                "to_frames": ([B * self.t_counts[q] * s_r * C for q in range(P)], [B * t_r * sc[q] * C for q in range(P)]),
+                "halo": (halo_in, list(halo_in))}
+
+    def selfcheck(self, device, levels=((9216, 320), (2304, 640), (576, 1280), (144, 1280)), C=8, log=None):
+        """Plumbing pass run by bench.py before any model work when N > 1: every collective signature of a sharded step, with the real
+        split structure of each UNet level (S tokens; C scaled down so the whole pass moves < 1 MB) and VALUE checks, synchronising after
+        each call so that an asynchronous RCCL failure is reported against the collective that caused it."""
+        def sync():
+            if torch.device(device).type == "cuda":
+                torch.cuda.synchronize()
+
+        def step(name, fn):
+            try:
+                fn()
+                sync()
+            except CollectiveError:
+                raise
+            except Exception as e:  # noqa: BLE001
+                raise CollectiveError(f"selfcheck step '{name}' failed on frame-shard rank {self.rank}/{self.P}: {type(e).__name__}: {e}") from e
+            if log:
+                log(f"selfcheck ok: {name}")
+        B, T, r = self.B, self.T, self.rank
+        t0 = self.t_off[r]
+
+        def stats():
+            s = torch.full((B * 64,), float(r + 1), dtype=torch.float32, device=device)  # the 5-D GroupNorm's 64 floats per clip
+            self.all_reduce_sum(s)
+            assert float(s[0]) == self.P * (self.P + 1) / 2, "all_reduce value"
+        step(f"all_reduce_sum {B * 64 * 4} B", stats)
+        for S, _ in levels:
+            def roundtrip(S=S):
+                # value = global (b, t, s) id, so a mis-routed chunk is caught, not just a size mismatch
+                ids = ((torch.arange(B)[:, None, None] * T + (t0 + torch.arange(self.t_local))[None, :, None]) * S + torch.arange(S)[None, None, :])
+                x = (ids.reshape(B * self.t_local, S, 1).float() + torch.arange(C).float() / 16).to(device)  # exact in fp32 (ids < 2^24)
+                xp = self.to_pixels(x)
+                so = offsets(self.pixel_counts(S))
+                want = ((torch.arange(B)[:, None, None] * T + torch.arange(T)[None, :, None]) * S + (so[r] + torch.arange(so[r + 1] - so[r]))[None, None, :])
+                assert torch.equal(xp[..., 0].cpu().float().reshape(-1), want.reshape(-1).float()), "to_pixels routed a chunk to the wrong place"
+                assert torch.equal(self.to_frames(xp, S), x), "to_frames(to_pixels(x)) != x"
+                xb = (x % 251).to(torch.bfloat16)  # the dtype the real step moves
+                assert torch.equal(self.to_frames(self.to_pixels(xb), S), xb), "bf16 round trip"
+            step(f"frame<->pixel all_to_all_single, S={S} (pixel slices {self.pixel_counts(S)})", roundtrip)
+
+            def halo(S=S):
+                h = torch.zeros((B * self.t_local, S, C), dtype=torch.bfloat16, device=device)
+                h.view(B, self.t_local, S, C)[:] = (t0 + torch.arange(self.t_local, device=device)).to(torch.bfloat16)[None, :, None, None]
+                prev, nxt = self.halo_exchange(h)
+                assert (prev is None) == (r == 0) and (nxt is None) == (r == self.P - 1)
+                assert prev is None or float(prev[0, 0, 0]) == t0 - 1
+                assert nxt is None or float(nxt[0, 0, 0]) == t0 + self.t_local
+            step(f"halo all_to_all_single with zero-length splits, S={S}", halo)
+
+        def gather():
+            g = self.gather_frames(torch.full((self.t_local, 3), float(r), device=device))
+            assert g.shape[0] == T and g[:, 0].tolist() == [float(q) for q in range(self.P) for _ in range(self.t_counts[q])]
+        step(f"all_gather of unequal frame counts {self.t_counts}", gather)
+        if self.cfg_pair is not None:
+            def pair():
+                both = self.exchange_cfg_halves(torch.full((self.t_local, 4, 2), float(self.cfg_half), device=device))
+                assert both.shape[0] == 2 * self.t_local and float(both[0, 0, 0]) == 0.0 and float(both[-1, 0, 0]) == 1.0
+            step("cfg-pair all_gather", pair)
+
     def to_pixels(self, x):
         """(B*t_local, S, C) frame-sharded -> (B*T, S_r, C) pixel-sharded (frames in global order)."""
         B, P = self.B, self.P
@@ -247,8 +352,7 @@ class FrameShard:
         pl = self._plan(S, x.device)
         sc, s_r = pl["sc"], pl["s_r"]
         send = x.reshape(n * S, C).index_select(0, pl["pack_fp"])
-        in_splits = [B * self.t_local * sc[q] * C for q in range(P)]
-        out_splits = [B * self.t_counts[q] * s_r * C for q in range(P)]
+        in_splits, out_splits = self.exchange_splits(S, C)["to_pixels"]
         recv = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
         self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
         return recv.view(-1, C).index_select(0, pl["unpack_fp"]).view(B * self.T, s_r, C)
@@ -262,8 +366,7 @@ class FrameShard:
         sc = pl["sc"]
         assert s_r == pl["s_r"]
         send = y.reshape(n * s_r, C).index_select(0, pl["pack_pf"])
-        in_splits = [B * self.t_counts[q] * s_r * C for q in range(P)]
-        out_splits = [B * self.t_local * sc[q] * C for q in range(P)]
+        in_splits, out_splits = self.exchange_splits(S, C)["to_frames"]
         recv = torch.empty(sum(out_splits), dtype=y.dtype, device=y.device)
         self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
         return recv.view(-1, C).index_select(0, pl["unpack_pf"]).view(B * self.t_local, S, C)
@@ -277,15 +380,12 @@ class FrameShard:
         assert n == B * t_l
         h4 = h.view(B, t_l, S, C)
         fs = B * S * C
-        parts, in_splits, out_splits = [], [0] * P, [0] * P
+        in_splits, out_splits = self.exchange_splits(S, C)["halo"]
+        parts = []
         if r > 0:
             parts.append(h4[:, 0].reshape(-1))
-            in_splits[r - 1] = fs
-            out_splits[r - 1] = fs
         if r < P - 1:
             parts.append(h4[:, t_l - 1].reshape(-1))
-            in_splits[r + 1] = fs
-            out_splits[r + 1] = fs
         send = torch.cat(parts) if parts else h.new_empty(0)
         recv = torch.empty(sum(out_splits), dtype=h.dtype, device=h.device)
         self.comm.all_to_all(recv, send, out_splits, in_splits)
