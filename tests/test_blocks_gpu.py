@@ -10,8 +10,9 @@ one block has 4-25 bf16 roundings, so its floor is 2-6e-3 and the bound is tight
 BASELINE config 5 (fp8 e4m3): the SAME blocks at the SAME shapes with the config's fp8 switches on, against the SAME
 fp32 oracle output (computed once per block). Re-stated tolerances, fp8 storage of GEMM operands with 3 mantissa bits
 (2^-4 = 6.3e-2 relative per element, averaged down by the K-sum) on residual branches:
-    ResBlock family with its four convolutions in fp8            :  rel-L2 <= 4e-2, max|err| <= 1.5e-1 * max|ref|
-    SpatialVideoTransformer with fp8 FeedForwards (+ attention / projections when those switches exist) : rel-L2 <= 4e-2, max <= 1.5e-1
+    ResBlock family with its four convolutions in fp8            :  rel-L2 <= 4e-2, max|err| <= 6e-2 * max|ref|   (measured 2.7-2.8e-2 / 2.5-3.0e-2)
+    SpatialVideoTransformer with fp8 FeedForwards (+ attention / projections when those switches exist) : rel-L2 <= 4e-2, max <= 6e-2
+                                                                                                            (FeedForwards: 2.6-2.7e-2 / 2.5-2.8e-2)
 Inputs are bf16-representable; weights are the seeded non-zero init of vista_amd.synth (every zero-init tensor re-randomised).
 One window = 25 frames of ONE clip (b = 1): the CFG-doubled batch of the bench is two independent copies of this.
 Measured values are appended to gpurun_out/block_parity.json when that directory exists."""
@@ -122,7 +123,7 @@ def test_video_resblock_at_baseline_shape(name, cin, cout, H, W):
     with torch.no_grad(), _fp8(["conv"]):  # BASELINE config 5: the block's four convolutions on e4m3 GroupNorm output
         out8 = blk(toks if len(toks) == 2 else toks[0], emb_silu, T, H, W)
     assert not torch.equal(out8, out), "the fp8 switch did not change the path"
-    _report("[fp8 conv] VideoResBlock " + name, _nchw(out8, T, H, W), ref, 4e-2, 1.5e-1, 0.0)
+    _report("[fp8 conv] VideoResBlock " + name, _nchw(out8, T, H, W), ref, 4e-2, 6e-2, 0.0)
     with torch.no_grad():
         assert torch.equal(blk(toks if len(toks) == 2 else toks[0], emb_silu, T, H, W), out), "switching fp8 off restores the bf16 path bit for bit"
 
@@ -161,7 +162,7 @@ def test_spatial_video_transformer_at_baseline_shape(name, C, H, W):
         with torch.no_grad(), _fp8(keys):
             out8 = blk(_tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W)
         assert not torch.equal(out8, out), "the fp8 switch did not change the path"
-        _report(f"[fp8 {'+'.join(keys)}] SpatialVideoTransformer " + name, _nchw(out8, T, H, W), ref, 4e-2, 1.5e-1, 0.0)
+        _report(f"[fp8 {'+'.join(keys)}] SpatialVideoTransformer " + name, _nchw(out8, T, H, W), ref, 4e-2, 6e-2, 0.0)
     with torch.no_grad():
         assert torch.equal(blk(_tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W), out)
 

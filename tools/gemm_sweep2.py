@@ -50,6 +50,13 @@ def main():
             "ff_out+res+stats": (lambda pw=ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C)): ops.linear(h4, pw, res1=res, emit_stats=True),
                                  2.0 * M * 4 * C * C),
             "conv3x3": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, N, H, W), 2.0 * M * 9 * C * C),
+            "conv3x3+emb": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)), rv=rn(N, C): ops.conv3x3(x3, pw, N, H, W, rowvec=rv),
+                            2.0 * M * 9 * C * C),
+            "conv3x3+res": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, N, H, W, res1=x3), 2.0 * M * 9 * C * C),
+            "ff_out+blend": (lambda pw=ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C)), rv=rn(N, C): ops.linear(
+                h4, pw, res1=res, alpha=0.4, res2=x, rowvec2=rv, beta=0.6, rows_per_vec=H * W), 2.0 * M * 4 * C * C),
+            "attn_out+ctx": (lambda pw=ops.pack_linear(rn(C, C) * C ** -0.5, rn(C)), rv=rn(N, C): ops.linear(
+                x, pw, res1=res, rowvec=rv, rows_per_vec=H * W, emit_stats=True), 2.0 * M * C * C),
             "conv_t3": (lambda pw=ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C)): ops.conv_t3(x3, pw, 25, H * W), 2.0 * M * 3 * C * C),
         }
         for name, (fn, flop) in cases.items():

@@ -51,8 +51,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     constexpr bool FRAG_DB = (NT <= 512) || (FX * FY <= 4);  // 16 waves x 32x160 wave tiles: no registers for double-buffered fragments
     // ONE LDS object (a second __shared__ array makes hipcc drain vmcnt before every K-step's first ds_read): two tile stages, then the
     // (mean, rstd) table of the tile's BM activation rows for the folded LayerNorm
-    constexpr int LN_OFF = 2 * STAGE_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + BM * 8];
+    // ... then the epilogue's per-column / per-image vectors (gemm_common.h, "LDS-staged epilogue")
+    constexpr int LN_OFF = 2 * STAGE_BYTES, EV_OFF = LN_OFF + BM * 8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + BM * 8 + epi_vec_floats(BN) * 4];
 
     const int tilesN = (p.N + BN - 1) / BN;
     const int tilesM = (p.M + BM - 1) / BM;
@@ -302,7 +303,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     // LDS-DMA pipeline: tile kt+1 streams straight into the free LDS stage while the MFMAs consume tile kt; the
     // barrier's vmcnt(0) retires the DMA. No staging VGPRs, no ds_write pass.
     float2* const lnrow_cur = (float2*)(smem + LN_OFF);
+    float* const epi_vec = (float*)(smem + EV_OFF);
+    const EpiPlan eplan = (ksplit > 1) ? EpiPlan{false, 0, 1} : epi_plan<EPI, OUT_F32, BM, BN>(p, m0, n0);
     dma_tile(kt0, kt0 & 1);
+    if (eplan.fast) epi_stage_vectors<BN, NT>(p, epi_vec, n0, eplan, tid);  // like the row statistics: under the first tile's DMA
     if (p.ln_stats != nullptr) {
         // row statistics of this tile's activation rows -> LDS. Issued AFTER the first tile's DMA so that both HBM round trips are in
         // flight together; visible to every wave after the barrier below.
@@ -331,7 +335,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             continue;  // (split-K launches are never persistent: one slice-tile per workgroup)
         }
     }
-    gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr);
+    if constexpr (!OUT_F32 && EPI == EPI_LINEAR) {
+        if (eplan.fast) gemm_epilogue_linear_lds<FX, FY, FM, FN, BN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr, epi_vec, eplan.img0);
+        else gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr);
+    } else if constexpr (EPI == EPI_GEGLU) {
+        if (eplan.fast) gemm_epilogue_geglu_lds<FX, FY, FM, FN, BN>(p, acc, m0, n0, wm, wn, l31, lh, p.ln_stats != nullptr ? lnrow_cur : nullptr, epi_vec);
+        else gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr);
+    } else {
+        gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr);
+    }
     if (PERSIST && bid + (int)gridDim.x < total_wg) __syncthreads();  // the next tile rewrites the LDS row-statistics table and stage 0
   } while (PERSIST && (bid += gridDim.x) < total_wg);
 }

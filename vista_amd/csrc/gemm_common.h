@@ -282,4 +282,244 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// LDS-staged epilogue (round 3). The disassembly of the round-2 epilogue showed what its fixed ~7-15 us per tile were: every accumulator
+// quad loaded its bias / LayerNorm column sums / row-vector float4s from global memory and WAITED for each (s_waitcnt vmcnt(0) after every
+// load: 2-4 dependent L2 round trips per quad, 20 quads per 32x160 wave tile), and every fragment's residual load sat behind the previous
+// fragment's stores (`out` may alias `res1` as far as the compiler can tell), i.e. five more dependent HBM round trips -- with all sixteen
+// waves of the CU in the epilogue at once and nothing to overlap them with. Here
+//   * the per-column vectors of the tile (bias, LayerNorm column sums) and the per-image row vectors of the <= EPI_NI images its rows span
+//     are staged into LDS ONCE per tile, at tile start, under the first K-step's DMA (one float4 per thread), and read back with ds_read_b128
+//     (lanes of a half-wave share the address: a broadcast read);
+//   * the residual loads of a row block are issued up front (a ring of `D` fragments ahead of the stores);
+//   * rows past M are clamped for the loads and predicated only at the stores, so the body is branch-free apart from kernel-uniform options.
+// Arithmetic and operation order are those of gemm_epilogue: results are bitwise the same.
+constexpr int EPI_NI = 4;  // images a tile's rows may span (256-row tiles: rows_per_vec >= 86)
+__host__ __device__ constexpr int epi_vec_floats(int bn) { return (2 + 2 * EPI_NI) * bn; }  // bias | colsum | EPI_NI x rowvec | EPI_NI x rowvec2
+
+struct EpiPlan {
+    bool fast;  // block-uniform: this tile takes the LDS-staged epilogue
+    int img0;   // first image (row-vector index) of the tile's rows
+    int nimg;
+};
+
+template <int EPI, bool OUT_F32, int BM, int BN>
+__device__ __forceinline__ EpiPlan epi_plan(const VkGemmDesc& p, int m0, int n0) {
+    EpiPlan e{false, 0, 1};
+    if (OUT_F32 || EPI == EPI_TRANS) return e;
+    if (n0 + BN > p.N || (p.ldc % 8) != 0 || (((size_t)p.out) & 15) != 0) return e;
+    // rows are addressed by 32-bit byte offsets from the (uniform) tensor bases
+    const unsigned long long lim = 0xfffff000ull, rows = (unsigned long long)p.M * 2ull;
+    if (rows * (unsigned)p.ldc >= lim || (p.res1 && rows * (unsigned)p.ld_res1 >= lim) || (p.res2 && rows * (unsigned)p.ld_res2 >= lim)) return e;
+    if (p.bias && (((size_t)p.bias) & 15) != 0) return e;
+    if (p.ln_stats && (((size_t)p.ln_colsum) & 15) != 0) return e;
+    if (EPI == EPI_GEGLU) { e.fast = true; return e; }  // (N % 32 == 0 is validated by the launcher; BN % 32 == 0)
+    if (p.res1 && ((p.ld_res1 % 8) != 0 || (((size_t)p.res1) & 15) != 0)) return e;
+    if (p.res2 && ((p.ld_res2 % 8) != 0 || (((size_t)p.res2) & 15) != 0)) return e;
+    if (p.rowvec || p.rowvec2) {
+        if ((p.ldv % 4) != 0 || (p.rowvec && (((size_t)p.rowvec) & 15) != 0) || (p.rowvec2 && (((size_t)p.rowvec2) & 15) != 0)) return e;
+        const int last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+        e.img0 = m0 / p.rows_per_vec;
+        e.nimg = last / p.rows_per_vec - e.img0 + 1;
+        if (e.nimg > EPI_NI) return e;
+    }
+    e.fast = true;
+    return e;
+}
+
+// one float4 per thread: section s of the region = [bias | colsum | rowvec of images img0.. | rowvec2 of images img0..], absent ones zero
+template <int BN, int NT>
+__device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev, int n0, const EpiPlan& e, int tid) {
+    constexpr int QN = BN / 4, NSEC = 2 + 2 * EPI_NI;
+#pragma unroll
+    for (int idx0 = 0; idx0 < NSEC * QN; idx0 += NT) {
+        const int idx = idx0 + tid;
+        if (idx < NSEC * QN) {
+            const int sec = idx / QN, q = idx - sec * QN;
+            const float* src = nullptr;
+            if (sec == 0) src = p.bias;
+            else if (sec == 1) src = p.ln_stats ? p.ln_colsum : nullptr;
+            else if (sec < 2 + EPI_NI) { if (p.rowvec && sec - 2 < e.nimg) src = p.rowvec + (size_t)(e.img0 + sec - 2) * p.ldv; }
+            else { if (p.rowvec2 && sec - 2 - EPI_NI < e.nimg) src = p.rowvec2 + (size_t)(e.img0 + sec - 2 - EPI_NI) * p.ldv; }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src) v = *(const float4*)(src + n0 + 4 * q);
+            *(float4*)(ev + sec * BN + 4 * q) = v;
+        }
+    }
+}
+
+// LINEAR, unit by unit over the wave tile's U = FX*FY fragments (row block fj, column fragment fi): LayerNorm fold / bias / row vector from
+// LDS, + res1, * alpha, + beta * (res2 + rowvec2), bf16 pack, row sums, two 16-byte stores. The residuals are the only global loads, issued
+// as a RING that runs ahead of the stores: DA units' loads go out before the first unit is touched, and every finished unit -- its residual
+// registers are dead then -- lets the next unit's loads go, so a load is in flight while the DA units before it are processed instead of
+// starting only after their stores. DA is sized by NRES, the number of residual tensors (0, 1 or 2: template, chosen by a kernel-uniform
+// branch), because the sixteen-wave kernels live at the 128-VGPR cap with 64-80 accumulator registers: a residual that had to be spilled
+// would be WAITED for at the spill, which is exactly the serialisation this epilogue removes. Absent row vectors are staged as zeros and
+// added unconditionally (x + 0 is exact); the LayerNorm fold is a template flag (two more ds_reads and eight fmas per quad).
+template <int NRES, bool LN, int FX, int FY, int FM, int FN, int BN>
+__device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
+                                                         int stat_part, const float2* lnrow, const float* ev, int img0) {
+    constexpr int MW = FM * 32, NW = FN * 32, U = FX * FY;
+    // ring depth: what fits beside the accumulators (16 registers per unit), ~36 registers of addresses / per-quad temporaries and the
+    // 128-VGPR cap, at 8 registers per unit and residual tensor
+    constexpr int ROOM = (128 - 16 * U - 36) / 8;
+    constexpr int DA = NRES == 0 ? 0 : ((ROOM / NRES < 1 ? 1 : ROOM / NRES) < U ? (ROOM / NRES < 1 ? 1 : ROOM / NRES) : U);
+    const bool a_is_r1 = p.res1 != nullptr;  // slot a = res1 if there is one, else res2; slot b = res2 when both exist
+    const uint16_t* __restrict__ ra = (const uint16_t*)(a_is_r1 ? p.res1 : p.res2);
+    const uint16_t* __restrict__ rb = (const uint16_t*)p.res2;
+    const int lda_ = a_is_r1 ? p.ld_res1 : p.ld_res2;
+    const int c0 = wn * NW + 4 * lh;             // tile-local column of this lane's quad 0 of fragment 0; quad g of fragment fi at + 32*fi + 8*g
+    const int wide_off = n0 + wn * NW + 8 * lh;  // the lane's 16-byte chunk of a 16-column group (widen_pair / unwiden_pair)
+    bool row_ok[FY];
+    int mrow[FY];
+    uint32_t rao[FY], rbo[FY], oo[FY];  // 32-bit BYTE offsets from the uniform bases (epi_plan checked the range): one register per row and tensor
+    char* const outb = (char*)p.out;
+#pragma unroll
+    for (int fj = 0; fj < FY; ++fj) {
+        const int m = m0 + wm * MW + fj * 32 + l31;
+        row_ok[fj] = m < p.M;
+        mrow[fj] = row_ok[fj] ? m : p.M - 1;  // loads of a row past M read the last row; only the stores are predicated
+        if (NRES >= 1) rao[fj] = ((uint32_t)mrow[fj] * (uint32_t)lda_ + (uint32_t)wide_off) * 2u;
+        if (NRES == 2) rbo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ld_res2 + (uint32_t)wide_off) * 2u;
+        oo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ldc + (uint32_t)wide_off) * 2u;
+    }
+    uint4 wa[U][2], wb[U][2];
+    auto issue = [&](int fj, int fi, int u) {
+        if (NRES >= 1) { wa[u][0] = *(const uint4*)((const char*)ra + rao[fj] + fi * 64); wa[u][1] = *(const uint4*)((const char*)ra + rao[fj] + fi * 64 + 32); }
+        if (NRES == 2) { wb[u][0] = *(const uint4*)((const char*)rb + rbo[fj] + fi * 64); wb[u][1] = *(const uint4*)((const char*)rb + rbo[fj] + fi * 64 + 32); }
+    };
+#pragma unroll
+    for (int u = 0; u < DA; ++u) issue(u / FX, u % FX, u);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int fj = 0; fj < FY; ++fj) {
+        float nrm = 0.f, rs = 1.f;
+        if (LN) { const float2 t = lnrow[mrow[fj] - m0]; rs = t.y; nrm = -t.x * t.y; }
+        const int iv = (p.rowvec || p.rowvec2) ? mrow[fj] / p.rows_per_vec - img0 : 0;
+        const float* evb = ev + c0;
+        const float* evc = ev + BN + c0;
+        const float* evr = ev + (2 + iv) * BN + c0;
+        const float* evr2 = ev + (2 + EPI_NI + iv) * BN + c0;
+        float ssum = 0.f, qsum = 0.f;
+#pragma unroll
+        for (int fi = 0; fi < FX; ++fi) {
+            const int u = fj * FX + fi;
+            uint2 packed[4], qa[4], qb[4];
+            if (NRES >= 1) { unwiden_pair(wa[u][0], qa[0], qa[1]); unwiden_pair(wa[u][1], qa[2], qa[3]); }
+            if (NRES == 2) { unwiden_pair(wb[u][0], qb[0], qb[1]); unwiden_pair(wb[u][1], qb[2], qb[3]); }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = fi * 32 + 8 * g;
+                const float4 b = *(const float4*)(evb + co);
+                const float4 rv = *(const float4*)(evr + co);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[fi][fj][4 * g + e];
+                if (LN) {
+                    const float4 c = *(const float4*)(evc + co);
+                    v[0] = fmaf(rs, v[0], fmaf(nrm, c.x, b.x)); v[1] = fmaf(rs, v[1], fmaf(nrm, c.y, b.y));
+                    v[2] = fmaf(rs, v[2], fmaf(nrm, c.z, b.z)); v[3] = fmaf(rs, v[3], fmaf(nrm, c.w, b.w));
+                } else {
+                    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                }
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                if (NRES >= 1 && a_is_r1) {
+                    const uint2 r = qa[g];
+                    v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+                if (NRES == 2 || (NRES == 1 && !a_is_r1)) {
+                    const uint2 r = NRES == 2 ? qb[g] : qa[g];
+                    const float4 b2 = *(const float4*)(evr2 + co);
+                    const float t0 = bf16_lo(r.x) + b2.x, t1 = bf16_hi(r.x) + b2.y, t2 = bf16_lo(r.y) + b2.z, t3 = bf16_hi(r.y) + b2.w;
+                    v[0] += p.beta * t0; v[1] += p.beta * t1; v[2] += p.beta * t2; v[3] += p.beta * t3;
+                }
+                packed[g].x = pack_bf16(v[0], v[1]);
+                packed[g].y = pack_bf16(v[2], v[3]);
+                if (p.rowstat_out) {
+                    const float a0 = bf16_lo(packed[g].x), a1 = bf16_hi(packed[g].x), a2 = bf16_lo(packed[g].y), a3 = bf16_hi(packed[g].y);
+                    ssum += (a0 + a1) + (a2 + a3);
+                    qsum = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, fmaf(a3, a3, qsum))));
+                }
+                // one quad's vectors in flight at a time: left alone, the scheduler hoists every ds_read of the row block and spills the
+                // residuals it was told to keep in flight
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const uint4 s0 = widen_pair(packed[0], packed[1]), s1 = widen_pair(packed[2], packed[3]);
+            if (row_ok[fj]) {
+                *(uint4*)(outb + oo[fj] + fi * 64) = s0;
+                *(uint4*)(outb + oo[fj] + fi * 64 + 32) = s1;
+            }
+            if (NRES >= 1 && u + DA < U) issue((u + DA) / FX, (u + DA) % FX, u + DA);  // this unit's residual registers are free again
+            __builtin_amdgcn_sched_barrier(0);  // keep the order: this unit's stores, the next ring slot's loads, the next unit
+        }
+        if (p.rowstat_out) {
+            const float so = __shfl_xor(ssum, 32, 64), qo = __shfl_xor(qsum, 32, 64);
+            if (lh == 0 && row_ok[fj]) ((float2*)p.rowstat_out)[(size_t)stat_part * p.M + mrow[fj]] = make_float2(ssum + so, qsum + qo);
+        }
+    }
+}
+
+template <int FX, int FY, int FM, int FN, int BN>
+__device__ __forceinline__ void gemm_epilogue_linear_lds(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
+                                                         int stat_part, const float2* lnrow, const float* ev, int img0) {
+    const int nres = (p.res1 != nullptr) + (p.res2 != nullptr);  // kernel-uniform
+#define VK_EPI_BODY(NR, LNF) epilogue_linear_lds_body<NR, LNF, FX, FY, FM, FN, BN>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0)
+    if (lnrow != nullptr) {
+        if (nres == 0) VK_EPI_BODY(0, true);
+        else if (nres == 1) VK_EPI_BODY(1, true);
+        else VK_EPI_BODY(2, true);
+    } else {
+        if (nres == 0) VK_EPI_BODY(0, false);
+        else if (nres == 1) VK_EPI_BODY(1, false);
+        else VK_EPI_BODY(2, false);
+    }
+#undef VK_EPI_BODY
+}
+
+template <int FX, int FY, int FM, int FN, int BN>
+__device__ __forceinline__ void gemm_epilogue_geglu_lds(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
+                                                        const float2* lnrow, const float* ev) {
+    constexpr int MW = FM * 32, NW = FN * 32;
+    const bool has_ln = lnrow != nullptr;
+    const float* evb = ev + wn * NW + 4 * lh;       // packed row of the value quad g of fragment fi: + 32*fi + 8*g; its gate 16 rows further
+    const float* evc = evb + BN;
+#pragma unroll
+    for (int fj = 0; fj < FY; ++fj) {
+        const int m = m0 + wm * MW + fj * 32 + l31;
+        const bool row_ok = m < p.M;
+        const int mc = row_ok ? m : p.M - 1;
+        float nrm = 0.f, rs = 1.f;
+        if (has_ln) { const float2 t = lnrow[mc - m0]; rs = t.y; nrm = -t.x * t.y; }
+        uint16_t* op = (uint16_t*)p.out + (size_t)mc * p.ldc + ((n0 + wn * NW) >> 1) + 8 * lh;
+#pragma unroll
+        for (int fi = 0; fi < FX; ++fi) {
+            uint2 packed[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int co = fi * 32 + 8 * g;
+                float a[4], gt[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = acc[fi][fj][4 * g + e]; gt[e] = acc[fi][fj][4 * (g + 2) + e]; }
+                const float4 ba = *(const float4*)(evb + co), bg = *(const float4*)(evb + co + 16);
+                if (has_ln) {
+                    const float4 ca = *(const float4*)(evc + co), cg = *(const float4*)(evc + co + 16);
+                    a[0] = fmaf(rs, a[0], fmaf(nrm, ca.x, ba.x)); a[1] = fmaf(rs, a[1], fmaf(nrm, ca.y, ba.y));
+                    a[2] = fmaf(rs, a[2], fmaf(nrm, ca.z, ba.z)); a[3] = fmaf(rs, a[3], fmaf(nrm, ca.w, ba.w));
+                    gt[0] = fmaf(rs, gt[0], fmaf(nrm, cg.x, bg.x)); gt[1] = fmaf(rs, gt[1], fmaf(nrm, cg.y, bg.y));
+                    gt[2] = fmaf(rs, gt[2], fmaf(nrm, cg.z, bg.z)); gt[3] = fmaf(rs, gt[3], fmaf(nrm, cg.w, bg.w));
+                } else {
+                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                    gt[0] += bg.x; gt[1] += bg.y; gt[2] += bg.z; gt[3] += bg.w;
+                }
+                packed[g].x = pack_bf16(a[0] * gelu_erf_f(gt[0]), a[1] * gelu_erf_f(gt[1]));
+                packed[g].y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
+            }
+            const uint4 w = widen_pair(packed[0], packed[1]);
+            if (row_ok) *(uint4*)(op + fi * 16) = w;
+        }
+    }
+}
+
 }  // namespace
