@@ -217,7 +217,7 @@ def oracle_50_step():
     sd = synth.seeded_state_dict(shapes, 0)
     T, H, W, steps = 5, 16, 32, 50
     w = synth.window_inputs(T=T, H=H, W=W, seed=31, n_cond=1, trajectory=TRAJ)
-    path = os.path.join(tempfile.gettempdir(), f"vista_oracle50_{synth.shapes_digest(shapes)[:12]}.pt")
+    path = os.path.join(tempfile.gettempdir(), f"vista_oracle50_{synth.shapes_digest(shapes):08x}.pt")
     if os.path.exists(path):
         want = torch.load(path)
     else:

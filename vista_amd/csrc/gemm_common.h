@@ -356,13 +356,13 @@ __device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev
 // branch), because the sixteen-wave kernels live at the 128-VGPR cap with 64-80 accumulator registers: a residual that had to be spilled
 // would be WAITED for at the spill, which is exactly the serialisation this epilogue removes. Absent row vectors are staged as zeros and
 // added unconditionally (x + 0 is exact); the LayerNorm fold is a template flag (two more ds_reads and eight fmas per quad).
-template <int NRES, bool LN, int FX, int FY, int FM, int FN, int BN>
+template <int NRES, bool LN, int FX, int FY, int FM, int FN, int BN, int CAP>
 __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
                                                          int stat_part, const float2* lnrow, const float* ev, int img0) {
     constexpr int MW = FM * 32, NW = FN * 32, U = FX * FY;
     // ring depth: what fits beside the accumulators (16 registers per unit), ~36 registers of addresses / per-quad temporaries and the
     // 128-VGPR cap, at 8 registers per unit and residual tensor
-    constexpr int ROOM = (128 - 16 * U - 36) / 8;
+    constexpr int ROOM = (CAP - 16 * U - 36) / 8;  // CAP: the kernel's VGPR budget (128 for sixteen waves, 256 for eight)
     constexpr int DA = NRES == 0 ? 0 : ((ROOM / NRES < 1 ? 1 : ROOM / NRES) < U ? (ROOM / NRES < 1 ? 1 : ROOM / NRES) : U);
     const bool a_is_r1 = p.res1 != nullptr;  // slot a = res1 if there is one, else res2; slot b = res2 when both exist
     const uint16_t* __restrict__ ra = (const uint16_t*)(a_is_r1 ? p.res1 : p.res2);
@@ -461,11 +461,11 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
     }
 }
 
-template <int FX, int FY, int FM, int FN, int BN>
+template <int FX, int FY, int FM, int FN, int BN, int CAP = 128>
 __device__ __forceinline__ void gemm_epilogue_linear_lds(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
                                                          int stat_part, const float2* lnrow, const float* ev, int img0) {
     const int nres = (p.res1 != nullptr) + (p.res2 != nullptr);  // kernel-uniform
-#define VK_EPI_BODY(NR, LNF) epilogue_linear_lds_body<NR, LNF, FX, FY, FM, FN, BN>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0)
+#define VK_EPI_BODY(NR, LNF) epilogue_linear_lds_body<NR, LNF, FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0)
     if (lnrow != nullptr) {
         if (nres == 0) VK_EPI_BODY(0, true);
         else if (nres == 1) VK_EPI_BODY(1, true);

@@ -60,7 +60,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
     static_assert(BM % RPP == 0 && BN % 8 == 0, "A rows must be a multiple of the staging pass, W rows of a wave's 8-row slice");
     constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
     constexpr int FX = FN, FY = FM;  // X = weights (MFMA row operand), Y = activations
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+    // two tile stages, then the LDS-staged epilogue's vectors (gemm_common.h) and the tile's BN per-channel weight scales
+    constexpr int EV_OFF = 2 * STAGE_BYTES, WS_OFF = EV_OFF + epi_vec_floats(BN) * 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + epi_vec_floats(BN) * 4 + BN * 4];
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -250,7 +252,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
     };
 
     const int nk = p.K / 128;
+    float* const epi_vec = (float*)(smem + EV_OFF);
+    float* const ws_lds = (float*)(smem + WS_OFF);
+    const EpiPlan eplan = epi_plan<EPI, OUT_F32, BM, BN>(p, m0, n0);
     dma_tile(0, 0);
+    if (eplan.fast) epi_stage_vectors<BN, NT>(p, epi_vec, n0, eplan, tid);  // under the first tile's DMA
+    for (int i = tid; i < BN / 4; i += NT) *(float4*)(ws_lds + 4 * i) = *(const float4*)(q.w_scale + n0 + 4 * i);  // (padded to the tile)
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int stage = kt & 1;
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
         for (int fi = 0; fi < FX; ++fi)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 s4 = *(const float4*)(q.w_scale + n0 + wn * NW + fi * 32 + 8 * g + 4 * lh);  // padded to the tile
+                const float4 s4 = *(const float4*)(ws_lds + wn * NW + fi * 32 + 8 * g + 4 * lh);
                 acc[fi][fj][4 * g + 0] *= sa * s4.x;
                 acc[fi][fj][4 * g + 1] *= sa * s4.y;
                 acc[fi][fj][4 * g + 2] *= sa * s4.z;
@@ -300,7 +307,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float a = acc[fp + f][fj][4 * g + e], gt = acc[fp + f][fj][4 * (g + 2) + e];
-                                if (bias) { a += bias[np + e]; gt += bias[np + 16 + e]; }
+                                if (eplan.fast) { a += epi_vec[np - n0 + e]; gt += epi_vec[np - n0 + 16 + e]; }  // bias staged in LDS (zeros if none)
+                                else if (bias) { a += bias[np + e]; gt += bias[np + 16 + e]; }
                                 const float v = a * gelu_erf_f(gt);
                                 h[f][g][e] = v;
                                 amax = fmaxf(amax, fabsf(v));
@@ -327,6 +335,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp
             }
             return;
         }
+    }
+    constexpr int CAP = (WM * WN == 16) ? 128 : 256;
+    if constexpr (!OUT_F32 && EPI == EPI_LINEAR) {
+        if (eplan.fast) { gemm_epilogue_linear_lds<FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, nullptr, epi_vec, eplan.img0); return; }
+    } else if constexpr (EPI == EPI_GEGLU) {
+        if (eplan.fast) { gemm_epilogue_geglu_lds<FX, FY, FM, FN, BN>(p, acc, m0, n0, wm, wn, l31, lh, nullptr, epi_vec); return; }
     }
     gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn);
 }
