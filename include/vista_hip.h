@@ -131,6 +131,12 @@ int vk_quantize_rows_fp8(const void* x, void* q, float* scale, int32_t M, int32_
 int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
                          int32_t S, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream);
 
+/* The same attention with V as a token-major column block [row][ldv] of the fused q|k|v projection (vwm/modules/attention.py:344-346 as ONE
+ * GEMM): no V^T tensor and no second pass over x -- the kernel transposes the V tile on its way out of LDS (ds_read_b64_tr_b16).
+ *   v : bf16, row (image*S + token) at v + row*ldv + head*64;  ldv % 8 == 0. Everything else as vk_attn_spatial_bf16. */
+int vk_attn_spatial_qkv_bf16(const void* q, const void* k, const void* v, void* o, int32_t n_img, int32_t heads,
+                             int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
+
 /* Temporal (cross-frame) self-attention over the T frames of every pixel: sequence length T <= 32, head dim 64.
  * Replaces the batchified xformers call at vwm/modules/attention.py:384-399 for VideoTransformerBlock.attn1
  * (vwm/modules/video_attention.py:116-127). Token rows are (b*T + t)*S + s; q,k,v are column blocks of one

@@ -207,6 +207,29 @@ def test_attn_spatial(n_img, heads, S):
     close(o, ref, f"attn_spatial S={S}", rtol=2e-2, arel=3e-2)
 
 
+@pytest.mark.parametrize("n_img,heads,S", [(2, 5, 144), (1, 2, 576), (3, 1, 64), (1, 5, 2304), (2, 3, 200), (1, 1, 9216),
+                                           (1, 2, 2048), (2, 1, 2120), (1, 1, 2056), (1, 3, 4104)])
+def test_attn_spatial_qkv_rows(n_img, heads, S):
+    """V as the third column block of ONE fused q|k|v GEMM (round 3: no V^T tensor; the kernel transposes the V tile out of LDS with
+    ds_read_b64_tr_b16) against fp32 SDPA, and BITWISE against the V^T form fed the transposed copy of the very same V values
+    (same fragments, same MFMA order: only the way the tile reaches the registers differs)."""
+    ops = _ops()
+    Cc = heads * 64
+    x = rnd(n_img * S, Cc, scale=1.0)
+    wq, wk, wv = (rnd(Cc, Cc, scale=1.5 * Cc ** -0.5, seed=s) for s in (1, 2, 3))
+    qkv = ops.linear(x, ops.pack_linear_cat([wq, wk, wv]))
+    assert qkv.shape == (n_img * S, 3 * Cc)
+    o = ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], n_img, heads, S, v_rows=True)
+    q, k, v = (qkv[:, i * Cc:(i + 1) * Cc].float().view(n_img, S, heads, 64).permute(0, 2, 1, 3) for i in range(3))
+    ref = _sdpa(q, k, v).permute(0, 2, 1, 3).reshape(n_img * S, Cc)
+    close(o, ref, f"attn_spatial q|k|v rows S={S}", rtol=2e-2, arel=3e-2)
+    vt = qkv[:, 2 * Cc:].reshape(n_img, S, Cc).transpose(1, 2).contiguous()   # (n_img, heads*64, S): the V^T image of the same values
+    o_vt = ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], vt, n_img, heads, S)
+    assert torch.equal(o, o_vt), "the transposing LDS read must deliver exactly the V^T fragments"
+    with pytest.raises(ValueError):
+        ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], vt, n_img, heads, S, v_rows=True)   # a V^T tensor passed as rows
+
+
 def test_attn_spatial_spike_forces_rescale():
     """One key row strongly aligned with one query row so the running max jumps mid-sequence (online-softmax rescale path)."""
     ops = _ops()

@@ -37,7 +37,7 @@ class VkGemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 2  # vk_abi_version() of the library this table mirrors
+ABI_VERSION = 3  # vk_abi_version() of the library this table mirrors
 
 # name -> argtypes; every entry returns int. Must list every symbol include/vista_hip.h declares
 # (tests/test_abi.py checks the header against this table and against the built library).
@@ -51,6 +51,7 @@ SIGNATURES = {
     "vk_groupnorm_silu_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_attn_spatial_qkv_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_temporal_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_softmax_rows_f32_bf16": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "vk_groupnorm_silu_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],

@@ -74,11 +74,16 @@ __device__ __forceinline__ float dot2_ones(uint32_t packed, float acc) {  // acc
 // NW waves per workgroup, QW 32-row query blocks per wave: NW*QW*32 query rows share each 64-key K / V^T tile. QW = 2 (long sequences)
 // feeds every K / V^T fragment read to TWO MFMAs: the K-loop of these kernels is LDS-throughput-bound (profiles/r02_ab_notes.txt A/B 2),
 // and the price -- twice the accumulators, 2 waves per SIMD instead of 4 -- is paid in latency hiding the loop does not depend on.
-template <int NW, int QW>
+// VROW: V is the token-major [S][ldv] column block of the fused q|k|v projection (no V^T tensor, no TRANS GEMM): its 64-key tile lands in LDS
+// as [key][64 d] rows and the PV MFMA's A operand (V^T fragment: row d, 8 consecutive keys) is read with ds_read_b64_tr_b16 -- per 16-lane
+// group a 4x16 -> 16x4 transpose of the 64 addressed bf16 (tools/probes/tr16_probe.hip), two reads per fragment. The lanes of a group
+// address 4 consecutive keys x 16 d; the 16-byte chunks of a row are swizzled by key bit 1 (swap of the 64-byte halves) so that the 4 rows
+// x 64 bytes a half-wave touches cover all 64 banks (tools/probes/tr16_layout_probe.hip: same rate as the b128 reads of the V^T image).
+template <int NW, int QW, bool VROW>
 __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                                 const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
                                                                                 int n_img, int heads, int S, int ldq, int ldk, int ldo,
-                                                                                float scale_log2, float rescale_thr) {
+                                                                                float scale_log2, float rescale_thr, int ldv) {
     constexpr int QB = NW * QW * 32;  // query rows per workgroup
     constexpr int GPW = 8 / NW;       // 8-row DMA groups of each tile handled per wave
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // per stage: K tile 8 KiB | V^T tile 8 KiB
@@ -119,7 +124,10 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
         d_row[i] = rho;                                           // V^T row = head-dim index d
     }
     const uint16_t* kbase = k + (size_t)img * S * ldk + head * 64;
-    const uint16_t* vbase = vt + ((size_t)(img * heads + head) * 64) * S;
+    const uint16_t* vbase = VROW ? vt + (size_t)img * S * ldv + head * 64 : vt + ((size_t)(img * heads + head) * 64) * S;
+    int v_chunk[GPW];  // VROW: logical 16-byte chunk of V row (= key) rho fetched into physical slot dslot
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) v_chunk[i] = dslot ^ (((d_row[i] >> 1) & 1) << 2);
 
     // Per-lane byte offsets inside a tile are loop-invariant; the tile itself moves the UNIFORM base (scalar adds), so a full tile costs
     // no per-lane address arithmetic. Only a ragged LAST tile needs the per-key bounds test (its missing keys read the zero word).
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
         k_off[i] = (uint32_t)(k_key[i] * ldk + src_chunk[i] * 8) * 2u;
-        v_off[i] = (uint32_t)(d_row[i] * S + src_chunk[i] * 8) * 2u;
+        v_off[i] = VROW ? (uint32_t)(d_row[i] * ldv + v_chunk[i] * 8) * 2u : (uint32_t)(d_row[i] * S + src_chunk[i] * 8) * 2u;
     }
     const bool ragged = (S & 63) != 0;
     const int n_tiles = (S + 63) >> 6;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
         char* sV = sK + 8192;
         if (NW == 8 && !(ragged && t == n_tiles - 1)) {  // (the 4-wave kernel of the short sequences has no registers to spare for it)
             const char* kt = (const char*)kbase + (size_t)key0 * ldk * 2;  // uniform
-            const char* vtile = (const char*)vbase + (size_t)key0 * 2;
+            const char* vtile = (const char*)vbase + (VROW ? (size_t)key0 * ldv * 2 : (size_t)key0 * 2);
 #pragma unroll
             for (int i = 0; i < GPW; ++i) {
                 __builtin_amdgcn_global_load_lds((gptr_t)(kt + k_off[i]), (lptr_t)(sK + i * NW * 1024), 16, 0, 0);
@@ -152,8 +160,9 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
             const int key = key0 + k_key[i];
             const uint16_t* ksrc = (key < S) ? kbase + (size_t)key * ldk + src_chunk[i] * 8 : (const uint16_t*)&g_attn_zero16;
             __builtin_amdgcn_global_load_lds((gptr_t)ksrc, (lptr_t)(sK + i * NW * 1024), 16, 0, 0);
-            const int kk = key0 + src_chunk[i] * 8;               // first key of this 8-key chunk (S % 8 == 0)
-            const uint16_t* vsrc = (kk < S) ? vbase + (size_t)d_row[i] * S + kk : (const uint16_t*)&g_attn_zero16;
+            const int kk = VROW ? key0 + d_row[i] : key0 + src_chunk[i] * 8;  // V row = key | first key of this 8-key chunk (S % 8 == 0)
+            const uint16_t* vsrc = (kk >= S) ? (const uint16_t*)&g_attn_zero16
+                                             : (VROW ? vbase + (size_t)kk * ldv + v_chunk[i] * 8 : vbase + (size_t)d_row[i] * S + kk);
             __builtin_amdgcn_global_load_lds((gptr_t)vsrc, (lptr_t)(sV + i * NW * 1024), 16, 0, 0);
         }
     };
@@ -163,6 +172,30 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
     int frag_off[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) frag_off[ks] = l31 * 128 + (((ks * 2 + lh) ^ fsw) << 4);
+
+    // VROW fragment reads: lane (l31, lh) of 16-lane group g1 = (l31 >> 4) & 1 addresses key 16J + 8lh + 4hf + kq (kq = (l31 & 15) >> 2), the 4 d at
+    // 32dd + 16 g1 + 4c (c = l31 & 3); key bit 1 = kq bit 1 swaps the row's 64-byte halves, i.e. flips dd. One base per dd, immediates for (J, hf).
+    int vtr_base[2];
+    {
+        const int kq = (l31 & 15) >> 2, g1 = (l31 >> 4) & 1, c = l31 & 3, sw1 = (kq >> 1) & 1;
+        const int b0 = (8 * lh + kq) * 128 + (2 * g1 + (c >> 1)) * 16 + (c & 1) * 8;
+        vtr_base[0] = b0 + (0 ^ sw1) * 64;
+        vtr_base[1] = b0 + (1 ^ sw1) * 64;
+    }
+    auto v_frag = [&](const char* sV, int d, int J) -> bf16x8_t {
+        if constexpr (VROW) {
+            typedef short s4_t __attribute__((ext_vector_type(4)));
+            typedef s4_t __attribute__((address_space(3))) * lds_s4_t;
+            const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sV + vtr_base[d] + J * 2048));
+            const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sV + vtr_base[d] + J * 2048 + 512));
+            bf16x8_t f;
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+            f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            return f;
+        } else {
+            return *(const bf16x8_t*)(sV + d * 32 * 128 + frag_off[J]);
+        }
+    };
 
     f32x16_t oacc[QW][2];
     float m_run[QW], l_run[QW];
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
         for (int d = 0; d < 2; ++d) {
 #pragma unroll
             for (int J = 0; J < 4; ++J) {
-                const bf16x8_t vf = *(const bf16x8_t*)(sV + d * 32 * 128 + frag_off[J]);
+                const bf16x8_t vf = v_frag(sV, d, J);
 #pragma unroll
                 for (int b = 0; b < QW; ++b) oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][J], oacc[b][d], 0, 0, 0);
             }
@@ -513,8 +546,8 @@ extern "C" int vk_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, i
     return VK_OK;
 }
 
-extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
-                                    int32_t S, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream_) {
+static int attn_spatial_launch(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
+                               int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream_) {
     if (!q || !k || !vt || !o || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;
     if ((S % 8) != 0 || (ldq % 8) != 0 || (ldk % 8) != 0 || (ldo % 4) != 0) return VK_EINVAL;
     // long sequences: 256 query rows (8 waves) per workgroup halve the K/V^T stream per FLOP; short ones keep 128 rows so the
@@ -528,15 +561,32 @@ extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt
     const int nqb = (S + qb_rows - 1) / qb_rows;
     const long long nblk = (long long)nqb * n_img * heads;
     if (nblk > 0x7fffffffLL) return VK_EINVAL;
-#define ATTN_LAUNCH(NW, QW)                                                                                                                 \
-    hipLaunchKernelGGL((attn_spatial_kernel<NW, QW>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint16_t*)q,       \
-                       (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr)
-    if (cls == 2) ATTN_LAUNCH(8, 2);
-    else if (cls == 1) ATTN_LAUNCH(8, 1);
-    else ATTN_LAUNCH(4, 1);
+#define ATTN_LAUNCH(NW, QW, VR)                                                                                                             \
+    hipLaunchKernelGGL((attn_spatial_kernel<NW, QW, VR>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint16_t*)q,   \
+                       (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr, ldv)
+    if (ldv > 0) {
+        if (cls == 2) ATTN_LAUNCH(8, 2, true);
+        else if (cls == 1) ATTN_LAUNCH(8, 1, true);
+        else ATTN_LAUNCH(4, 1, true);
+    } else {
+        if (cls == 2) ATTN_LAUNCH(8, 2, false);
+        else if (cls == 1) ATTN_LAUNCH(8, 1, false);
+        else ATTN_LAUNCH(4, 1, false);
+    }
 #undef ATTN_LAUNCH
     VK_CHECK_LAUNCH();
     return VK_OK;
+}
+
+extern "C" int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
+                                    int32_t S, int32_t ldq, int32_t ldk, int32_t ldo, float scale, void* stream_) {
+    return attn_spatial_launch(q, k, vt, o, n_img, heads, S, ldq, ldk, 0, ldo, scale, stream_);
+}
+
+extern "C" int vk_attn_spatial_qkv_bf16(const void* q, const void* k, const void* v, void* o, int32_t n_img, int32_t heads,
+                                        int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream_) {
+    if (ldv <= 0 || (ldv % 8) != 0) return VK_EINVAL;
+    return attn_spatial_launch(q, k, v, o, n_img, heads, S, ldq, ldk, ldv, ldo, scale, stream_);
 }
 
 extern "C" int vk_attn_temporal_bf16(const void* qkv, void* o, int32_t B, int32_t T, int32_t S, int32_t heads, int32_t ld,

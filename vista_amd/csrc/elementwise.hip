@@ -317,4 +317,4 @@ extern "C" int vk_ensemble_variance_sum(const float* x, double* out, double* par
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
-extern "C" int vk_abi_version(void) { return 2; }
+extern "C" int vk_abi_version(void) { return 3; }

@@ -4,7 +4,7 @@ Same classes, constructor arguments and state-dict names as the reference; `forw
 activations ((n_img*S, C), C contiguous) and runs entirely on the HIP kernels of libvista_hip.so:
 
   BasicTransformerBlock (attention.py:514-524)
-      x += to_out(softmax(q k^T/8) v)        LN -> fused [q|k] GEMM + V^T GEMM -> vk_attn_spatial_bf16 -> out GEMM(+res)
+      x += to_out(softmax(q k^T/8) v)        LN folded -> ONE fused q|k|v GEMM -> vk_attn_spatial_qkv_bf16 -> out GEMM(+res)
       x += attn2(norm2(x), context)          context is ONE token (CLIP (+) action embeddings), so softmax == 1 and the
                                              output is to_out(to_v(ctx) + v_adapter(ctx_act)) for every query
                                              (attention.py:341-353,400-421): computed per image by two tiny GEMMs and
@@ -113,6 +113,9 @@ class GEGLU(nn.Module):
 # out-projection, 32 % of the UNet's FLOPs -- in fp8 e4m3 with per-token activation scales and per-channel weight scales.
 # "conv": additionally the ResBlock convolutions (2-D 3x3 and temporal 3x1x1) on e4m3 GroupNorm output (openaimodel.py ResBlock).
 FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1", "conv": os.environ.get("VISTA_FP8_CONV", "0") == "1"}
+
+
+QKV_SPLIT = os.environ.get("VISTA_QKV_SPLIT", "0") == "1"  # A/B hook: spatial self-attention's projections as in round 2 (q|k + V^T GEMMs)
 
 
 class FeedForward(nn.Module, Packable):
@@ -258,13 +261,16 @@ class BasicTransformerBlock(nn.Module, Packable):
         self.n_heads, self.dim = n_heads, dim
 
     def _pack(self, dev):
-        # LayerNorms folded into the GEMMs that consume them (norm1 -> q|k and v^T projections, norm3 -> GEGLU): the block owns the
+        # LayerNorms folded into the GEMMs that consume them (norm1 -> the fused q|k|v projection, norm3 -> GEGLU): the block owns the
         # norms, so it packs those weights; attn1 / ff keep their own out-projections. norm2 only feeds the 1-token cross-attention's
         # query, which cannot influence the output (softmax over one key == 1).
         a = self.attn1
-        return {"qk": ops.pack_linear_cat([a.to_q.weight, a.to_k.weight], dev, ln=self.norm1),
-                "v": ops.pack_linear(a.to_v.weight, None, dev, ln=self.norm1),
-                "ff_in": self.ff.pack_in_folded(self.norm3, dev)}
+        pk = {"qkv": ops.pack_linear_cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dev, ln=self.norm1),
+              "ff_in": self.ff.pack_in_folded(self.norm3, dev)}
+        if QKV_SPLIT:  # same-box A/B hook only: the round-2 form (q|k GEMM + V^T GEMM, a second pass over x)
+            pk["qk"] = ops.pack_linear_cat([a.to_q.weight, a.to_k.weight], dev, ln=self.norm1)
+            pk["v"] = ops.pack_linear(a.to_v.weight, None, dev, ln=self.norm1)
+        return pk
 
     def forward(self, x, stats, context, n_img, S, out_rowvec=None, emit_stats=True):
         """x: (n_img*S, dim) bf16 tokens with their RowStats; context: (n_img, ctx_width) bf16 (one context token per image).
@@ -273,9 +279,15 @@ class BasicTransformerBlock(nn.Module, Packable):
         pk = self.packed()
         a1 = self.attn1.packed()
         C = self.dim
-        qk = ops.linear(x, pk["qk"], ln=stats)            # LayerNorm(norm1) folded: x is read, never a normalised copy
-        vt = ops.linear_vt(x, pk["v"], S, ln=stats)
-        att = ops.attn_spatial(qk[:, :C], qk[:, C:], vt, n_img, self.n_heads, S, self.attn1.dim_head ** -0.5)
+        if QKV_SPLIT:
+            qk = ops.linear(x, pk["qk"], ln=stats)
+            vt = ops.linear_vt(x, pk["v"], S, ln=stats)
+            att = ops.attn_spatial(qk[:, :C], qk[:, C:], vt, n_img, self.n_heads, S, self.attn1.dim_head ** -0.5)
+        else:
+            # ONE q|k|v GEMM (attention.py:344-346), LayerNorm(norm1) folded: x is read once and never as a normalised copy; the attention
+            # kernel takes V as the third column block and transposes its tiles on the way out of LDS (no V^T tensor, no TRANS GEMM)
+            qkv = ops.linear(x, pk["qkv"], ln=stats)
+            att = ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_img, self.n_heads, S, self.attn1.dim_head ** -0.5, v_rows=True)
         cv = self.attn2.context_vector(context)  # attn2(norm2(x), context): constant over the image's tokens
         x, st = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=S, emit_stats=True)
         r = self.ff.forward_folded(x, st, pk["ff_in"], self.norm3, res1=x, rowvec=out_rowvec, rows_per_vec=S, emit_stats=emit_stats)
