@@ -58,6 +58,8 @@ typedef struct VkGemmDesc {
     /* ---- producer side of the same fold: emit the row sums of the bf16-rounded OUTPUT of this GEMM (EPI_LINEAR, bf16 out) ---- */
     float* rowstat_out;  /* f32 [vk_gemm_rowstat_parts(desc)][M][2] or NULL; one slab per (column tile, wave column)               */
     const float* rowvec2; /* f32 [M/rows_per_vec][ldv] or NULL, added with beta: out = alpha*(...) + beta*(res2 + rowvec2[row/rows_per_vec]) */
+    int32_t act;         /* EPI_LINEAR: 0 = none; 1 = exact-erf GELU applied to (acc + bias + rowvec) BEFORE res1 / alpha -- the MLP of the
+                            conditioner's OpenCLIP image tower: c_fc -> nn.GELU -> c_proj (vwm/modules/encoders/modules.py:273-279)           */
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
@@ -137,6 +139,22 @@ int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, 
 int vk_attn_spatial_qkv_bf16(const void* q, const void* k, const void* v, void* o, int32_t n_img, int32_t heads,
                              int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
 
+/* Small dense attention, any head dim D in {64, 80, 128}: softmax(q k^T * scale) v per (image, head); q / k / v are column blocks of one
+ * row-major buffer (q at qkv + row*ld + head*D, k at + k_off, v at + v_off; row = image*S + token). The nn.MultiheadAttention of the
+ * conditioner's OpenCLIP ViT-H/14 image tower (FrozenOpenCLIPImageEmbedder, vwm/modules/encoders/modules.py:251-399: 257 tokens, 16 heads
+ * of dim 80). 4*S*D bytes of LDS (<= 160 KiB). */
+int vk_attn_small_bf16(const void* qkv, void* o, int32_t n_img, int32_t heads, int32_t S, int32_t D, int32_t ld, int32_t k_off,
+                       int32_t v_off, int32_t ldo, float scale, void* stream);
+
+/* OpenCLIP image preprocessing + patchify (FrozenOpenCLIPImageEmbedder.preprocess, modules.py:304-315, and the im2col of the tower's
+ * patch convolution): kornia-0.6.9 antialiased bicubic resize of img f32 [n][3][H][W] in [-1, 1] to out_hw x out_hw (Gaussian blur with
+ * (sigma_y, sigma_x) / odd kernel sizes (ks_y, ks_x) <= 15, reflect border, then bicubic align_corners=True), (x + 1) / 2, CLIP mean / std
+ * (HOST arrays of 3 floats), written as the bf16 A operand of the patch-embedding GEMM:
+ *   out[(img * (1 + g*g) + 1 + py*g + px) * ldo + c*patch*patch + ky*patch + kx],  g = out_hw / patch.
+ * Only those columns are written: the caller zero-fills `out` (class-token row of every image, K padding) once. */
+int vk_clip_preprocess_patches(const float* img, void* out, int32_t n_img, int32_t H, int32_t W, int32_t out_hw, int32_t patch, int32_t ldo,
+                               float sigma_y, float sigma_x, int32_t ks_y, int32_t ks_x, const float* mean3, const float* std3, void* stream);
+
 /* Temporal (cross-frame) self-attention over the T frames of every pixel: sequence length T <= 32, head dim 64.
  * Replaces the batchified xformers call at vwm/modules/attention.py:384-399 for VideoTransformerBlock.attn1
  * (vwm/modules/video_attention.py:116-127). Token rows are (b*T + t)*S + s; q,k,v are column blocks of one
@@ -201,6 +219,8 @@ int vk_tokens_to_nchw_f32(const float* x, float* out, int32_t n_img, int32_t C, 
 /* sinusoidal timestep embedding: out[n][0:half]=cos(t[n]*f_j), out[n][half:]=sin(t[n]*f_j), f_j=exp(-ln(max_period)*j/half)
  * (vwm/modules/diffusionmodules/util.py:141-165); bf16 output feeds the embedding MLPs */
 int vk_timestep_embedding_bf16(const float* t, void* out, int32_t n, int32_t dim, float max_period, void* stream);
+/* The same sinusoid in fp32: ConcatTimestepEmbedderND of the conditioner (vwm/modules/encoders/modules.py:402-425 over openaimodel.py Timestep). */
+int vk_timestep_embedding_f32(const float* t, float* out, int32_t n, int32_t dim, float max_period, void* stream);
 
 /* emb = a*mask[n] + b*(1-mask[n]) + c  (video_model.py:457-471); writes emb (f32) and silu(emb) (bf16, the input
  * of every ResBlock emb_layers: openaimodel.py:222-225). a may be NULL (no cond-frame mask: emb = b + c). */

@@ -56,10 +56,24 @@ def test_reference_vista_yaml_builds_this_package_unchanged_and_overlay_differs_
             elif k == "target":
                 out[pre + k] = v
         return out
-    for key in ("network_config", "denoiser_config"):
-        for path, t in targets(ours[key]).items():
-            rt = targets(rp[key])[path]
-            assert t == rt.replace("vwm.modules.", "vista_amd.modules."), (path, t, rt)
+    def strip(d):  # the config without its target strings
+        if isinstance(d, dict):
+            return {k: strip(v) for k, v in d.items() if k != "target"}
+        return [strip(v) for v in d] if isinstance(d, list) else d
+
+    def targets_l(d, pre=""):  # targets() that also walks the emb_models LIST of the conditioner
+        out = {}
+        for k, v in (d.items() if isinstance(d, dict) else enumerate(d)):
+            if isinstance(v, (dict, list)):
+                out.update(targets_l(v, f"{pre}{k}."))
+            elif k == "target":
+                out[pre + k] = v
+        return out
+    for key in ("network_config", "denoiser_config", "conditioner_config"):
+        for path, t in targets_l(ours[key]).items():
+            rt = targets_l(rp[key])[path]
+            assert t == rt.replace("vwm.modules.", "vista_amd.modules.").replace("vwm.models.", "vista_amd.models."), (path, t, rt)
+    assert strip(ours["conditioner_config"]) == strip(rp["conditioner_config"]), "the conditioner entry differs from vista.yaml:42-140 only in targets"
     merged = config.overlay(ref, {"model": config.load_config()["model"]})
-    assert merged["model"]["params"]["conditioner_config"] == rp["conditioner_config"], "everything off the hot path stays the reference's"
+    assert merged["model"]["params"]["first_stage_config"] == rp["first_stage_config"], "everything this package does not replace stays the reference's"
     assert merged["model"]["params"]["network_config"]["target"].startswith("vista_amd.")

@@ -33,7 +33,7 @@ class VkGemmDesc(C.Structure):
         ("T", _i32), ("S", _i32), ("tile_cfg", _i32), ("halo_prev", _vp), ("halo_next", _vp), ("splitk_ws", _vp), ("splitk_ws_bytes", _i64), ("asym_pad", _i32),
         ("k_split", _i32), ("A2", _vp), ("lda2", _i32),
         ("ln_parts", _i32), ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_eps", _f32),
-        ("rowstat_out", _vp), ("rowvec2", _vp),
+        ("rowstat_out", _vp), ("rowvec2", _vp), ("act", _i32),
     ]
 
 
@@ -52,6 +52,8 @@ SIGNATURES = {
     "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_spatial_qkv_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_attn_small_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_clip_preprocess_patches": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _vp],
     "vk_attn_temporal_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_softmax_rows_f32_bf16": [_vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "vk_groupnorm_silu_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
@@ -64,6 +66,7 @@ SIGNATURES = {
     "vk_nchw_to_tokens_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vk_tokens_to_nchw_f32": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vk_timestep_embedding_bf16": [_vp, _vp, _i32, _i32, _f32, _vp],
+    "vk_timestep_embedding_f32": [_vp, _vp, _i32, _i32, _f32, _vp],
     "vk_emb_combine": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp],
     "vk_silu_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "vk_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],

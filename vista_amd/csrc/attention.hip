@@ -546,6 +546,94 @@ extern "C" int vk_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, i
     return VK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Small dense attention for the conditioner's OpenCLIP ViT-H/14 image tower (vwm/modules/encoders/modules.py:251-399 -> open_clip
+// VisionTransformer resblocks: nn.MultiheadAttention over 257 tokens, 16 heads of dim 80): softmax(q k^T * scale) v per (image, head),
+// any head dim D <= 128 that is a multiple of 8, S up to a few hundred tokens. It runs once per sampling window on a handful of images
+// (0.1 % of a window's FLOPs), so it is a plain fp32 VALU kernel: one thread per query row, the head's K and V slices staged once per
+// workgroup in LDS as bf16 (broadcast reads), online softmax in registers.
+namespace {
+template <int D>
+__global__ __launch_bounds__(64) void attn_small_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o, int heads, int S, int ld,
+                                                        int k_off, int v_off, int ldo, float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];  // K [S][D] bf16 | V [S][D] bf16
+    uint16_t* sK = (uint16_t*)dsm;
+    uint16_t* sV = sK + (size_t)S * D;
+    const int bh = blockIdx.x, img = bh / heads, head = bh - img * heads;
+    const uint16_t* base = qkv + (size_t)img * S * ld + head * D;
+    constexpr int CH = D / 8;  // 16-byte chunks per row
+    for (int i = threadIdx.x; i < S * CH; i += 64) {
+        const int r = i / CH, c = i - r * CH;
+        *(uint4*)(sK + (size_t)r * D + c * 8) = *(const uint4*)(base + (size_t)r * ld + k_off + c * 8);
+        *(uint4*)(sV + (size_t)r * D + c * 8) = *(const uint4*)(base + (size_t)r * ld + v_off + c * 8);
+    }
+    __syncthreads();
+    const int s = blockIdx.y * 64 + threadIdx.x;
+    if (s >= S) return;
+    float q[D], acc[D];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        float f[8];
+        unpack8(*(const uint4*)(base + (size_t)s * ld + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { q[8 * c + e] = f[e] * scale_log2; acc[8 * c + e] = 0.f; }
+    }
+    float m = NEG_BIG, l = 0.f;
+    for (int j = 0; j < S; ++j) {
+        float sc = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float f[8];
+            unpack8(*(const uint4*)(sK + (size_t)j * D + c * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc = fmaf(q[8 * c + e], f[e], sc);
+        }
+        const float m_new = fmaxf(m, sc);
+        const float alpha = fast_exp2(m - m_new), pj = fast_exp2(sc - m_new);
+        m = m_new;
+        l = fmaf(l, alpha, pj);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            float f[8];
+            unpack8(*(const uint4*)(sV + (size_t)j * D + c * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[8 * c + e] = fmaf(acc[8 * c + e], alpha, pj * f[e]);
+        }
+    }
+    const float inv = 1.f / l;
+    uint16_t* op = o + ((size_t)img * S + s) * ldo + head * D;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = acc[8 * c + e] * inv;
+        *(uint4*)(op + c * 8) = pack8(f);
+    }
+}
+}  // namespace
+
+extern "C" int vk_attn_small_bf16(const void* qkv, void* o, int32_t n_img, int32_t heads, int32_t S, int32_t D, int32_t ld, int32_t k_off,
+                                  int32_t v_off, int32_t ldo, float scale, void* stream_) {
+    if (!qkv || !o || n_img <= 0 || heads <= 0 || S <= 0 || (ld % 8) != 0 || (k_off % 8) != 0 || (v_off % 8) != 0 || (ldo % 8) != 0) return VK_EINVAL;
+    const size_t lds = (size_t)S * D * 2 * 2;
+    if (lds > 160 * 1024) return VK_EINVAL;
+    const dim3 grid((unsigned)(n_img * heads), (unsigned)((S + 63) / 64));
+#define SMALL_LAUNCH(DD)                                                                                                                      \
+    do {                                                                                                                                       \
+        if (lds > 64 * 1024 && hipFuncSetAttribute((const void*)attn_small_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return VK_ELAUNCH;                                                                                                                 \
+        hipLaunchKernelGGL((attn_small_kernel<DD>), grid, dim3(64), lds, (hipStream_t)stream_, (const uint16_t*)qkv, (uint16_t*)o, heads, S, ld,  \
+                           k_off, v_off, ldo, scale * LOG2E);                                                                                  \
+    } while (0)
+    if (D == 80) SMALL_LAUNCH(80);
+    else if (D == 64) SMALL_LAUNCH(64);
+    else if (D == 128) SMALL_LAUNCH(128);
+    else return VK_EINVAL;
+#undef SMALL_LAUNCH
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
 static int attn_spatial_launch(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
                                int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream_) {
     if (!q || !k || !vt || !o || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;

@@ -57,7 +57,8 @@ __global__ void tokens_to_nchw_kernel(const float* __restrict__ x, float* __rest
     }
 }
 
-__global__ void timestep_embedding_kernel(const float* __restrict__ t, uint16_t* __restrict__ out, int n, int dim, float neg_log_period) {
+template <bool F32>
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, void* __restrict__ out_, int n, int dim, float neg_log_period) {
     const int half = dim >> 1;
     const long long tot = (long long)n * dim;
     GRID_STRIDE(i, tot) {
@@ -70,7 +71,8 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, uint16_t*
             const float arg = t[r] * freq;
             v = (j < half) ? cosf(arg) : sinf(arg);
         }
-        out[i] = f32_to_bf16(v);
+        if (F32) ((float*)out_)[i] = v;
+        else ((uint16_t*)out_)[i] = f32_to_bf16(v);
     }
 }
 
@@ -233,6 +235,67 @@ __global__ void ens_var_final_kernel(const double* __restrict__ partial, double*
     out[0] = a;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// OpenCLIP image preprocessing + patchify in one pass (FrozenOpenCLIPImageEmbedder.preprocess, vwm/modules/encoders/modules.py:304-315,
+// then the 14x14 / stride-14 patch convolution's im2col): kornia 0.6.9 `resize(x, (224, 224), "bicubic", align_corners=True, antialias=True)`
+// = separable Gaussian blur (reflect border; sigma = (factor - 1) / 2 per axis, kernel size int(max(4 sigma, 3)) made odd -- only when
+// downscaling) followed by F.interpolate(mode="bicubic", align_corners=True) (A = -0.75, clamped taps); then (x + 1) / 2 and the CLIP
+// mean / std. One thread per output pixel; its value is written straight into the patch-embedding GEMM's A operand:
+//   out[(img * (1 + gp*gp) + 1 + py*gp + px)][c*ps*ps + ky*ps + kx]   bf16, row stride ldo (columns 3*ps*ps .. ldo-1 zero), row 0 of each
+//   image (the class-token slot) zero.
+__device__ __forceinline__ float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
+__device__ __forceinline__ float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
+__device__ __forceinline__ int reflect_idx(int i, int n) { i = i < 0 ? -i : i; return i >= n ? 2 * (n - 1) - i : i; }
+
+__global__ __launch_bounds__(EW_THREADS) void clip_preprocess_kernel(const float* __restrict__ img, uint16_t* __restrict__ out, int n_img, int H, int W,
+                                                                     int out_hw, int ps, int ldo, float sig_y, float sig_x, int ks_y, int ks_x,
+                                                                     float m0, float m1, float m2, float s0, float s1, float s2) {
+    const int gp = out_hw / ps;
+    const long long total = (long long)n_img * 3 * out_hw * out_hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % out_hw);
+        const int oy = (int)((i / out_hw) % out_hw);
+        const int c = (int)((i / ((long long)out_hw * out_hw)) % 3);
+        const int n = (int)(i / ((long long)3 * out_hw * out_hw));
+        const float* src = img + ((size_t)n * 3 + c) * H * W;
+        const float ry = out_hw > 1 ? (float)oy * ((float)(H - 1) / (float)(out_hw - 1)) : 0.f;
+        const float rx = out_hw > 1 ? (float)ox * ((float)(W - 1) / (float)(out_hw - 1)) : 0.f;
+        const int iy = (int)floorf(ry), ix = (int)floorf(rx);
+        const float ty = ry - (float)iy, tx = rx - (float)ix;
+        const float A = -0.75f;
+        const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
+        const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
+        // Gaussian taps (normalised); ks == 1 means no blur (no downscaling along that axis)
+        float gy[15], gx[15], ny = 0.f, nx = 0.f;
+        for (int k = 0; k < ks_y; ++k) { const float d = (float)(k - ks_y / 2); gy[k] = ks_y > 1 ? expf(-d * d / (2.f * sig_y * sig_y)) : 1.f; ny += gy[k]; }
+        for (int k = 0; k < ks_x; ++k) { const float d = (float)(k - ks_x / 2); gx[k] = ks_x > 1 ? expf(-d * d / (2.f * sig_x * sig_x)) : 1.f; nx += gx[k]; }
+        float acc = 0.f;
+        for (int a = 0; a < 4; ++a) {
+            int yy = iy - 1 + a;
+            yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);  // bicubic taps are clamped to the (blurred) image
+            float rowacc = 0.f;
+            for (int b = 0; b < 4; ++b) {
+                int xx = ix - 1 + b;
+                xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                float v = 0.f;  // blurred(yy, xx): reflect-padded separable Gaussian
+                for (int ky = 0; ky < ks_y; ++ky) {
+                    const float* row = src + (size_t)reflect_idx(yy + ky - ks_y / 2, H) * W;
+                    float r = 0.f;
+                    for (int kx = 0; kx < ks_x; ++kx) r = fmaf(gx[kx], row[reflect_idx(xx + kx - ks_x / 2, W)], r);
+                    v = fmaf(gy[ky], r, v);
+                }
+                rowacc = fmaf(wx[b], v / (ny * nx), rowacc);
+            }
+            acc = fmaf(wy[a], rowacc, acc);
+        }
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        const float val = ((acc + 1.f) * 0.5f - mean) / sd;
+        const int py = oy / ps, ky = oy - py * ps, px = ox / ps, kx = ox - px * ps;
+        out[((size_t)n * (1 + gp * gp) + 1 + py * gp + px) * ldo + (c * ps + ky) * ps + kx] = f32_to_bf16(val);
+    }
+}
+
 }  // namespace
 
 #define EW_LAUNCH(kernel, count, ...)                                                                          \
@@ -254,7 +317,11 @@ extern "C" int vk_tokens_to_nchw_f32(const float* x, float* out, int32_t n_img, 
 }
 extern "C" int vk_timestep_embedding_bf16(const float* t, void* out, int32_t n, int32_t dim, float max_period, void* stream) {
     if (!t || !out || n <= 0 || dim < 2 || max_period <= 0.f) return VK_EINVAL;
-    EW_LAUNCH(timestep_embedding_kernel, (long long)n * dim, t, (uint16_t*)out, n, dim, -logf(max_period));
+    EW_LAUNCH(timestep_embedding_kernel<false>, (long long)n * dim, t, out, n, dim, -logf(max_period));
+}
+extern "C" int vk_timestep_embedding_f32(const float* t, float* out, int32_t n, int32_t dim, float max_period, void* stream) {
+    if (!t || !out || n <= 0 || dim < 2 || max_period <= 0.f) return VK_EINVAL;
+    EW_LAUNCH(timestep_embedding_kernel<true>, (long long)n * dim, t, (void*)out, n, dim, -logf(max_period));
 }
 extern "C" int vk_emb_combine(const float* a, const float* b, const float* c, const float* mask, float* emb, void* silu_out, int32_t n,
                               int32_t dim, void* stream) {
@@ -316,5 +383,15 @@ extern "C" int vk_ensemble_variance_sum(const float* x, double* out, double* par
     hipLaunchKernelGGL(ens_var_final_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const double*)partial_ws, out, nblk);
     VK_CHECK_LAUNCH();
     return VK_OK;
+}
+extern "C" int vk_clip_preprocess_patches(const float* img, void* out, int32_t n_img, int32_t H, int32_t W, int32_t out_hw, int32_t patch,
+                                          int32_t ldo, float sigma_y, float sigma_x, int32_t ks_y, int32_t ks_x, const float* mean3,
+                                          const float* std3, void* stream) {
+    if (!img || !out || !mean3 || !std3 || n_img <= 0 || H < 2 || W < 2 || out_hw <= 0 || patch <= 0 || (out_hw % patch) != 0 ||
+        ldo < 3 * patch * patch || ks_y < 1 || ks_x < 1 || ks_y > 15 || ks_x > 15 || !(ks_y & 1) || !(ks_x & 1) || !(sigma_y > 0.f) || !(sigma_x > 0.f))
+        return VK_EINVAL;
+    // the caller zero-fills `out` once (class-token rows and the K padding); this launch writes the 3*patch*patch image columns
+    EW_LAUNCH(clip_preprocess_kernel, (long long)n_img * 3 * out_hw * out_hw, img, (uint16_t*)out, n_img, H, W, out_hw, patch, ldo, sigma_y, sigma_x,
+              ks_y, ks_x, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
 }
 extern "C" int vk_abi_version(void) { return 3; }

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
             q.ldc = p.N;
             q.bias = nullptr; q.rowvec = nullptr; q.res1 = nullptr; q.res2 = nullptr;
             q.alpha = 1.f; q.beta = 0.f;
-            q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr;
+            q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr; q.act = 0;
             gemm_epilogue<EPI_LINEAR, true, FX, FY, FM, FN>(q, acc, m0, n0, wm, wn, l31, lh);
             continue;  // (split-K launches are never persistent: one slice-tile per workgroup)
         }
@@ -445,7 +445,7 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     // tiles x slices ~ one full round of CUs; fp32 partials go to the caller's workspace and a finishing pass applies the epilogue.
     // Not combined with the LayerNorm fold / row-sum emission (their epilogues need the finished accumulator in registers).
     int ksplit = 1;
-    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && !d->ln_stats && !d->rowstat_out) {
+    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && !d->ln_stats && !d->rowstat_out && !d->act) {
         const bool ok320s = (amode != AMODE_CONV3D) && (d->N % 320 == 0);
         const int bn = ok320s ? 320 : 256;
         const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
@@ -498,6 +498,7 @@ inline int validate(const VkGemmDesc* d) {
     if (d->A2 && (d->amode != AMODE_DENSE || d->k_split <= 0 || d->k_split >= d->K || (d->k_split % BK) != 0 || (d->lda2 % 8) != 0)) return VK_EINVAL;
     if (d->ln_stats && (d->amode != AMODE_DENSE || d->A2 || !d->ln_colsum || d->ln_parts <= 0 || d->ln_parts > 64 || !(d->ln_eps > 0.f))) return VK_EINVAL;
     if (d->rowstat_out && (d->epi != EPI_LINEAR || d->out_f32)) return VK_EINVAL;
+    if (d->act != 0 && (d->act != 1 || d->epi != EPI_LINEAR)) return VK_EINVAL;
     return VK_OK;
 }
 

@@ -138,6 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                         const float4 b = *(const float4*)(rv + n);
                         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                     }
+                    if (p.act == 1) { v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]); }
                     if (res1) {
                         const uint2 r = r1q[g];
                         v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
@@ -423,6 +424,7 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                 }
                 v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                if (p.act == 1) { v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]); }
                 if (NRES >= 1 && a_is_r1) {
                     const uint2 r = qa[g];
                     v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);

@@ -42,3 +42,45 @@ class AutoencodingEngine(nn.Module):
     def decode(self, z, **kwargs):
         """autoencoder.py:206-208"""
         return self.decoder(z, **kwargs)
+
+
+class AutoencoderKLModeOnly(nn.Module):
+    """vwm/models/autoencoder.py:432-529 (AutoencodingEngineLegacy with a mode-only DiagonalGaussianRegularizer) as the conditioner uses
+    it (configs/inference/vista.yaml:71-95, `VideoPredictionEmbedderWithEncoder(is_ae=True)`): encode(x) = mean of
+    quant_conv(encoder(x)). The 1x1 `quant_conv` directly follows the encoder's 3x3 `conv_out` with nothing in between, so the two are
+    ONE 3x3 convolution (W' = W_q W_c, b' = W_q b_c + b_q, composed in fp32 at pack time). The legacy class also owns a decoder and a
+    post_quant_conv that inference never calls; they are not built (their checkpoint keys are reported as unexpected by
+    load_state_dict(strict=False), like every unused key of the reference)."""
+
+    def __init__(self, embed_dim, ddconfig, **ignored):
+        super().__init__()
+        from ..modules.attention import Packable  # noqa: F401
+        from ..modules.diffusionmodules.model import Encoder
+        from ..modules.diffusionmodules.util import ConvNd
+        self.encoder = Encoder(**ddconfig)
+        zc = (2 if ddconfig.get("double_z", True) else 1)
+        self.quant_conv = ConvNd(zc * ddconfig["z_channels"], zc * embed_dim, (1, 1))
+        self.embed_dim, self.double_z = embed_dim, bool(ddconfig.get("double_z", True))
+        self._pk, self._pk_key = None, None
+
+    def _packed(self):
+        co, qc = self.encoder.conv_out, self.quant_conv
+        ps = (co.weight, co.bias, qc.weight, qc.bias)
+        key = tuple((id(p), p.device, 0 if p.is_inference() else p._version) for p in ps)
+        if self._pk is None or self._pk_key != key:
+            with torch.no_grad():
+                wq = qc.weight.detach().float()[:, :, 0, 0]                                     # (out, 8)
+                w = torch.einsum("om,mikl->oikl", wq, co.weight.detach().float())               # (out, C, 3, 3)
+                b = wq @ co.bias.detach().float() + qc.bias.detach().float()
+                self._pk, self._pk_key = ops.pack_conv3x3(w, b, device=co.weight.device), key
+        return self._pk
+
+    def encode(self, x, return_reg_log=False, scale=1.0):
+        h, H, W = self.encoder.features(x)
+        n = h.shape[0]
+        mom, _, _ = ops.conv3x3(h, self._packed(), n, H, W, out_f32=True)                      # (n, H*W, >= 2*embed) f32 moments, token-major
+        nz = self.embed_dim
+        z = ops.tokens_to_nchw(mom, n, nz, H, W)                                               # mode = the mean half (distributions.py:24-37)
+        if scale != 1.0:
+            z = ops.scale_rows(z, torch.full((n,), float(scale), device=z.device))
+        return (z, {}) if return_reg_log else z

@@ -132,9 +132,11 @@ class AttnBlock(nn.Module, Packable):
 
 
 def make_attn(in_channels, attn_type="vanilla", attn_kwargs=None):
-    """model.py:244-271: vista.yaml selects `vanilla`."""
-    if attn_type != "vanilla":
-        raise NotImplementedError(f"attn_type {attn_type!r}: Vista's first stage uses 'vanilla'")
+    """model.py:244-271: vista.yaml selects `vanilla` for the first stage and `vanilla-xformers` for the conditioner's encoder copy
+    (MemoryEfficientAttnBlock, model.py:179-232: the same parameters -- norm, q, k, v, proj_out -- and the same single-head
+    softmax(q k^T / sqrt(C)) v, only computed by xformers there): one class serves both."""
+    if attn_type not in ("vanilla", "vanilla-xformers"):
+        raise NotImplementedError(f"attn_type {attn_type!r}: Vista uses 'vanilla' / 'vanilla-xformers'")
     assert attn_kwargs is None
     return AttnBlock(in_channels)
 
@@ -279,6 +281,12 @@ class Encoder(nn.Module, Packable):
         return r
 
     def forward(self, x):
+        h, H, W = self.features(x)
+        return self.conv_out(h, H, W)
+
+    def features(self, x):
+        """Everything up to (and including) norm_out + swish: ((n, H'*W', C) bf16 tokens, H', W'). `conv_out` follows; the mode-only
+        autoencoder of the conditioner composes its 1x1 quant_conv into that convolution (models/autoencoder.AutoencoderKLModeOnly)."""
         if x.device.type != "cuda":
             raise ops._lib.VistaHipError("Encoder: images must be on the MI355X (vista_amd has no CPU path)")
         n_img, _, H, W = x.shape
@@ -295,7 +303,7 @@ class Encoder(nn.Module, Packable):
         h = self.mid.attn_1(h, H, W)
         h = self.mid.block_2(h, None, H, W)
         h = ops.groupnorm(h, self.norm_out.weight, self.norm_out.bias, self.norm_out.eps, silu=True)
-        return self.conv_out(h, H, W)
+        return h, H, W
 
 
 class _Conv2dOut(ConvNd, Packable):

@@ -247,8 +247,8 @@ def _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta,
 
 
 def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0, rowvec2=None,
-           x2=None, ln=None, emit_stats=False):
-    """out = alpha*(X @ W^T + bias + rowvec[row // rows_per_vec] + res1) + beta*(res2 + rowvec2[row // rows_per_vec]).
+           x2=None, ln=None, emit_stats=False, act=None):
+    """out = alpha*(act(X @ W^T + bias + rowvec[row // rows_per_vec]) + res1) + beta*(res2 + rowvec2[row // rows_per_vec]); act: None | "gelu".
     x: (..., K) bf16. x2: second source of a channel concat, X = [x | x2] (never materialised). ln: RowStats of x's rows when pw has
     a LayerNorm folded in (X = LayerNorm(x)). emit_stats: also return the RowStats of the (bf16) output -> (out, stats)."""
     _need(x, BF16, "x")
@@ -276,6 +276,10 @@ def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=
     d.epi = EPI_GEGLU if pw.geglu else EPI_LINEAR
     _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta, rowvec2)
     _fill_ln(d, pw, ln, M)
+    if act is not None:
+        if act != "gelu" or pw.geglu:
+            raise ValueError("linear: act must be None or 'gelu' (exact-erf GELU in the LINEAR epilogue)")
+        d.act = 1
     stats = _gemm(d, emit_stats, x.device)
     return (out, stats) if emit_stats else out
 
@@ -623,6 +627,54 @@ def attn_spatial(q, k, vt, n_img, heads, S, scale=None, v_rows=False):
     return o
 
 
+def attn_small(qkv, n_img, heads, S, D, scale=None):
+    """qkv: (n_img*S, 3*heads*D) bf16 row-major [q | k | v]; softmax(q k^T * scale) v per (image, head), D in {64, 80, 128}
+    (the OpenCLIP image tower's nn.MultiheadAttention). Returns (n_img*S, heads*D)."""
+    _need(qkv, BF16, "qkv")
+    c = heads * D
+    if qkv.dim() != 2 or qkv.stride(1) != 1 or qkv.shape != (n_img * S, 3 * c):
+        raise ValueError(f"attn_small: qkv must be (n_img*S, 3*heads*D) = {(n_img * S, 3 * c)} with contiguous rows, got {tuple(qkv.shape)}")
+    o = torch.empty((n_img * S, c), dtype=BF16, device=qkv.device)
+    check(_lib.load().vk_attn_small_bf16(_p(qkv), _p(o), n_img, heads, S, D, qkv.stride(0), c, 2 * c, o.stride(0),
+                                         float(scale if scale is not None else 1.0 / math.sqrt(D)), _stream()), "vk_attn_small_bf16")
+    return o
+
+
+def antialias_blur_params(in_size, out_size):
+    """(sigma, kernel size) of kornia-0.6.9 `resize(..., antialias=True)` along one axis (kornia/geometry/transform/affwarp.py: the
+    blur only exists when downscaling; sigma = max((factor - 1) / 2, 0.001), ks = int(max(4 sigma, 3)) made odd). No blur: (1.0, 1)."""
+    factor = in_size / out_size
+    sigma = max((factor - 1.0) / 2.0, 0.001)
+    ks = int(max(2.0 * 2 * sigma, 3))
+    if ks % 2 == 0:
+        ks += 1
+    return sigma, ks
+
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def clip_preprocess_patches(img, out_hw=224, patch=14, kpad=None, antialias=True, mean=CLIP_MEAN, std=CLIP_STD):
+    """img (n, 3, H, W) f32 in [-1, 1] -> (n * (1 + g*g), Kp) bf16, g = out_hw / patch: row 0 of every image zero (class-token slot), row
+    1 + py*g + px = patch (py, px) of the resized / normalised image flattened [c][ky][kx], zero-padded to Kp = ceil64(3*patch^2).
+    FrozenOpenCLIPImageEmbedder.preprocess (modules.py:304-315) fused with the patch convolution's im2col."""
+    _need(img, F32, "img")
+    img = img.contiguous()
+    n, c, H, W = img.shape
+    if c != 3:
+        raise ValueError("clip_preprocess_patches: 3-channel images")
+    g = out_hw // patch
+    kp = kpad or ceil_to(3 * patch * patch, 64)
+    out = torch.zeros((n * (1 + g * g), kp), dtype=BF16, device=img.device)
+    down = antialias and max(H / out_hw, W / out_hw) > 1  # kornia blurs BOTH axes as soon as either one is downscaled
+    (sy, ky), (sx, kx) = (antialias_blur_params(H, out_hw), antialias_blur_params(W, out_hw)) if down else ((1.0, 1), (1.0, 1))
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(_lib.load().vk_clip_preprocess_patches(_p(img), _p(out), n, H, W, out_hw, patch, kp, sy, sx, ky, kx, m3, s3, _stream()),
+          "vk_clip_preprocess_patches")
+    return out
+
+
 def attn_temporal(qkv, B, T, S, heads, scale=None):
     """qkv: ((b t) s, 3*heads*64) bf16 row-major [q | k | v]. Returns ((b t) s, heads*64)."""
     _need(qkv, BF16, "qkv")
@@ -737,12 +789,13 @@ def tokens_to_nchw(x, n_img, Cc, H, W):
     return out
 
 
-def timestep_embedding(t, dim, max_period=10000.0):
+def timestep_embedding(t, dim, max_period=10000.0, out_f32=False):
     _need(t, F32, "t")
     t = t.contiguous()
-    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
-    check(_lib.load().vk_timestep_embedding_bf16(_p(t), _p(out), t.shape[0], dim, float(max_period), _stream()),
-          "vk_timestep_embedding_bf16")
+    out = torch.empty((t.shape[0], dim), dtype=F32 if out_f32 else BF16, device=t.device)
+    lib = _lib.load()
+    fn = lib.vk_timestep_embedding_f32 if out_f32 else lib.vk_timestep_embedding_bf16
+    check(fn(_p(t), _p(out), t.shape[0], dim, float(max_period), _stream()), "vk_timestep_embedding")
     return out
 
 

@@ -8,9 +8,11 @@ the decoded third-from-last frame feeds the image embedder) and contributes `num
     model.model / model.denoiser        network wrapper and Denoiser (called as model.denoiser(model.model, x, sigma, cond, mask))
     model.decode_first_stage(z)         latents -> images            model.encode_first_stage(x)   images -> latents
     model.scale_factor                  model.conditioner.embedders  (skip_encode toggling)        model.ema_scope(...)
-The conditioner itself (OpenCLIP / VAE-encoder embedders) is out of scope here: pass `get_condition`
-(same signature as sample_utils.get_condition) or give the pipeline a `condition_fn`.
+The conditioner (vista_amd.modules.encoders.modules.GeneralConditioner: OpenCLIP image tower, first-stage encoder, sinusoid embedders --
+SURVEY.md 8f rank 2) plugs in as `VistaPipeline(conditioner=...)`: `get_condition` / `get_batch` below are the reference's
+(sample_utils.py:232-276). A caller may still pass its own `get_condition` (same signature) or give the pipeline a `condition_fn`.
 """
+import math
 import contextlib
 
 import torch
@@ -31,12 +33,14 @@ class VistaPipeline:
     """The attributes of DiffusionEngine that `do_sample` touches, over vista_amd modules."""
 
     def __init__(self, network, denoiser, decoder=None, encode_fn=None, condition_fn=None, scale_factor=0.18215,
-                 en_and_decode_n_samples_a_time=14):
+                 en_and_decode_n_samples_a_time=14, conditioner=None):
         self.model, self.denoiser = network, denoiser
         self.decoder, self.encode_fn, self.condition_fn = decoder, encode_fn, condition_fn
         self.scale_factor = scale_factor
         self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
-        self.conditioner = _NoEmbedders()
+        self.conditioner = conditioner if conditioner is not None else _NoEmbedders()
+        if conditioner is not None and condition_fn is None:
+            self.condition_fn = get_condition
 
     def ema_scope(self, *_a, **_k):
         return contextlib.nullcontext()
@@ -56,6 +60,42 @@ class _NoEmbedders:
     embedders = ()
 
 
+def get_batch(keys, value_dict, N, device="cuda"):
+    """sample_utils.py:232-253: per-key batch tensors of the demo setups -- scalars (fps_id, motion_bucket_id, cond_aug) repeated prod(N)
+    times, action vectors and conditioning frames repeated N[0] times; batch_uc is a clone."""
+    batch = {}
+    for key in keys:
+        if key not in value_dict:
+            continue
+        if key in ("fps", "fps_id", "motion_bucket_id", "cond_aug"):
+            batch[key] = torch.tensor([value_dict[key]]).to(device).repeat(math.prod(N))
+        elif key in ("command", "trajectory", "speed", "angle", "goal"):
+            v = value_dict[key][None].to(device)
+            batch[key] = v.repeat(N[0], *([1] * (v.dim() - 1)))
+        elif key in ("cond_frames", "cond_frames_without_noise"):
+            v = value_dict[key]
+            batch[key] = v.repeat(N[0], *([1] * (v.dim() - 1)))
+        else:
+            raise NotImplementedError(key)
+    batch_uc = {k: torch.clone(v) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    return batch, batch_uc
+
+
+def get_condition(model, value_dict, num_samples, force_uc_zero_embeddings, device):
+    """sample_utils.py:256-276 (without the load_model / unload_model host<->device shuffling: 288 GB of HBM keep the conditioner resident)."""
+    keys = list({e.input_key for e in model.conditioner.embedders if getattr(e, "input_key", None) is not None})
+    batch, batch_uc = get_batch(keys, value_dict, [num_samples], device)
+    c, uc = model.conditioner.get_unconditional_conditioning(batch, batch_uc=batch_uc, force_uc_zero_embeddings=force_uc_zero_embeddings)
+    for k in c:
+        if isinstance(c[k], torch.Tensor):
+            c[k], uc[k] = c[k][:num_samples].to(device), uc[k][:num_samples].to(device)
+            if c[k].shape[0] < num_samples:
+                c[k] = c[k][[0]]
+            if uc[k].shape[0] < num_samples:
+                uc[k] = uc[k][[0]]
+    return c, uc
+
+
 def _set_skip_encode(model, flag):
     for emb in model.conditioner.embedders:
         if hasattr(emb, "skip_encode"):
@@ -73,7 +113,7 @@ def do_sample(images, model, sampler, value_dict, num_rounds, num_frames, force_
     force_uc_zero_embeddings = [] if force_uc_zero_embeddings is None else force_uc_zero_embeddings
     get_condition = get_condition or getattr(model, "condition_fn", None)
     if get_condition is None:
-        raise ValueError("do_sample: no conditioner -- pass get_condition= (vista_amd does not rebuild the OpenCLIP/VAE embedders)")
+        raise ValueError("do_sample: no conditioner -- build the pipeline with conditioner=GeneralConditioner(...) or pass get_condition=")
     noise_fn = noise_fn or torch.randn_like
     carry = 3                                  # frames handed from one window to the next
     fresh = num_frames - carry                 # new frames every later round contributes

@@ -6,7 +6,7 @@ import importlib
 
 import torch
 
-_TARGET_PREFIXES = (("vwm.modules.", "vista_amd.modules."), ("vwm.util", "vista_amd.util"))
+_TARGET_PREFIXES = (("vwm.modules.", "vista_amd.modules."), ("vwm.models.", "vista_amd.models."), ("vwm.util", "vista_amd.util"))
 
 
 def default(val, d):
