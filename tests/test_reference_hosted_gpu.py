@@ -1,0 +1,78 @@
+"""INTEGRATION.md section 2, executed: the REFERENCE's own EulerEDMSampler + Denoiser + OpenAIWrapper (unmodified files, imported through
+oracle/ref_shim.py -- test side only) drive vista_amd's VideoUNet on the MI355X under torch.autocast("cuda"), exactly as sample_utils.py:285-333
+would after the two-line `target:` edit, and the result is held to the golden the reference produced with ITS OWN UNet on CPU
+(tests/golden/sampler_tiny.pt, oracle/make_golden.py).
+
+Needs the reference tree (VISTA_REFERENCE, default /root/reference): skipped on the driver's GPU box, where it is not mounted. Run once per
+round through gpurun with the handful of reference files the sampler imports shipped as temporary, git-ignored test data
+(tools/ship_reference_for_test.sh); the log is kept under profiles/."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_shim  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_shim.available(), reason="reference tree not mounted (set VISTA_REFERENCE)")]
+GOLD = os.path.join(ROOT, "tests", "golden")
+TRAJ = [0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2]
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).pow(2).sum().sqrt() / b.float().pow(2).sum().sqrt()).item()
+
+
+def test_reference_sampler_denoiser_wrapper_drive_the_vista_amd_unet():
+    import contextlib
+    import io
+    import json
+    ref_shim.install()
+    with contextlib.redirect_stdout(io.StringIO()):
+        from vwm.modules.diffusionmodules.denoiser import Denoiser as RefDenoiser
+        from vwm.modules.diffusionmodules.sampling import EulerEDMSampler as RefSampler
+        from vwm.modules.diffusionmodules.wrappers import OpenAIWrapper as RefWrapper
+    for cls in (RefDenoiser, RefSampler, RefWrapper):
+        assert sys.modules[cls.__module__].__file__.startswith(ref_shim.REF_ROOT), "these must be the reference's own files"
+    from vista_amd import synth
+    from vista_amd.config import unet_kwargs
+    from vista_amd.modules.diffusionmodules.video_model import VideoUNet
+    g = torch.load(os.path.join(GOLD, "sampler_tiny.pt"))
+    T, H, W = g["T"], g["H"], g["W"]
+    net = VideoUNet(**unet_kwargs(64))
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert synth.shapes_digest(shapes) == g["digest"]
+    net.load_state_dict(synth.seeded_state_dict(shapes, g["seed_w"]), strict=True)
+    net = net.cuda().eval()
+    wrapper = RefWrapper(net)                                              # reference wrappers.py:10-40 around THIS package's network
+    P = "vwm.modules.diffusionmodules."                                    # resolved by the REFERENCE's instantiate_from_config to the reference's classes
+    den = RefDenoiser(scaling_config={"target": P + "denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1, trajectory=TRAJ)
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
+    res = {}
+    for name, gcfg in (("vanilla", {"target": P + "guiders.VanillaCFG", "params": {"scale": 2.5}}),
+                       ("triangle", {"target": P + "guiders.TrianglePredictionGuider", "params": {"num_frames": T, "max_scale": 2.5, "min_scale": 1.0}})):
+        sampler = RefSampler(num_steps=g["steps"], discretization_config={"target": P + "discretizer.EDMDiscretization",
+                                                                          "params": {"sigma_min": 0.002, "sigma_max": 700.0, "rho": 7.0}},
+                             guider_config=gcfg, s_churn=0.0, s_tmin=0.0, s_tmax=999.0, s_noise=1.0, verbose=False, device="cuda")
+        assert type(sampler.guider).__module__.startswith("vwm.")
+
+        def denoiser(x, sigma, cond, cond_mask):                            # the closure of sample_utils.py:314-315
+            return den(wrapper, x, sigma, cond, cond_mask)
+        noise = w["noise"].clone().cuda()
+        with torch.no_grad(), torch.autocast("cuda"):                       # sample_utils.py:285,303
+            out = sampler(denoiser, noise, cond=cu(w["c"]), uc=cu(w["uc"]), cond_frame=w["cond_frame"].cuda(), cond_mask=w["cond_mask"].cuda())
+        out = out.float().cpu()
+        r = rel_l2(out, g[name])
+        res[name] = r
+        print(f"[reference-hosted] reference EulerEDMSampler/Denoiser/OpenAIWrapper x vista_amd VideoUNet, {name}, {g['steps']} steps under autocast: "
+              f"rel-L2 {r:.4e} vs the all-reference CPU golden")
+        assert torch.isfinite(out).all() and r <= 4e-2
+        assert torch.equal(out[0], w["cond_frame"][0])
+        assert torch.allclose(noise.cpu(), g[name + "_noise_after"], rtol=1e-5, atol=1e-5)
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        json.dump({"what": "reference sampler stack around vista_amd VideoUNet on the MI355X under torch.autocast", "rel_l2": res},
+                  open(os.path.join(d, "reference_hosted.json"), "w"))
