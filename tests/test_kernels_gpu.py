@@ -391,7 +391,7 @@ def test_sampler_elementwise():
 
 
 # ------------------------------------------------------------------------------------------------ block-tile variants
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
 def test_gemm_family_all_tile_configs(cfg):
     """Every block-tile variant (128x128, 256x128, 256x256, 256x320) of every loader / epilogue, on shapes with ragged M and N edges."""
     ops = _ops()
@@ -530,7 +530,7 @@ def _check_stats(st, out):
     assert (got - ref).abs().le(tol).all(), f"row sums off by {(got - ref).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(777, 320, 320), (300, 640, 1280), (513, 1280, 640), (100, 64, 128)])
 def test_linear_emit_rowstats(cfg, M, N, K):
     ops = _ops()
@@ -561,7 +561,7 @@ def test_rowstats(rows, C):
     _check_stats(ops.rowstats(big[:, C:]), big[:, C:])  # strided rows
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,C,N", [(600, 320, 640), (300, 1280, 1280), (130, 64, 192)])
 def test_linear_layernorm_fold(cfg, M, C, N):
     """Linear(LayerNorm(x)) with the norm folded into the GEMM: x has a LARGE row mean (the fold subtracts mean * colsum in the epilogue)."""

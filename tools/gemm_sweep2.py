@@ -1,6 +1,6 @@
-"""Round-2 A/B sweep of the GEMM main-loop experiment bits (ops.TILE_FLAGS: 8 = staggered DMA issue, 16 = MFMA priority) on the BASELINE
-shapes, including the folded-LayerNorm consumers and the row-sum emitting producers. Interleaved rounds, best of 3 x 10 launches per
-variant; one JSON line per shape: TFLOP/s by flag value.   usage: python tools/gemm_sweep2.py [flags,flags,...]"""
+"""A/B sweep of GEMM block-tile choices (ops.TILE_CFG: 0 = auto, 1..5 = forced) on the BASELINE shapes, including the folded-LayerNorm consumers,
+the row-sum emitting producers and the residual / row-vector epilogues. Interleaved rounds, best of 3 x 10 launches per variant; one JSON line per
+shape: TFLOP/s and ms by variant.   usage: python tools/gemm_sweep2.py [cfg,cfg,...]   (tools/ab_sweep.sh alternates two LIBRARY builds on cfg 0)"""
 import json
 import os
 import sys
@@ -31,7 +31,7 @@ def timeit(fn, iters=10):
 
 
 def main():
-    flags = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0".split(","))]  # experiment bits (attribute ops.TILE_FLAGS, honoured only by builds that carry an experiment)
+    flags = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0".split(","))]  # values of ops.TILE_CFG to compare (0 = the launcher's own choice; 1..5 force a block tile)
     N = 50
     rn = lambda *s: torch.randn(*s, device="cuda")  # noqa: E731
     for C, H, W in ((320, 72, 128), (640, 36, 64), (1280, 18, 32)):
@@ -63,9 +63,9 @@ def main():
             best = {}
             for _ in range(3):
                 for f in flags:
-                    ops.TILE_FLAGS = f
+                    ops.TILE_CFG = f
                     best[f] = min(best.get(f, 1e9), timeit(fn))
-            ops.TILE_FLAGS = 0
+            ops.TILE_CFG = 0
             print(json.dumps({"level_C": C, "kind": name, "M": M, "TFLOPs_by_flags": {str(f): round(flop / ms / 1e9) for f, ms in best.items()},
                               "ms_by_flags": {str(f): round(ms, 4) for f, ms in best.items()}}), flush=True)
         del x, res, h4, cases

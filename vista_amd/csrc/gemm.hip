@@ -28,12 +28,19 @@
 // The MFMA is issued "swapped" (weights are the row/A operand, activations the column/B operand) so that a lane
 // owns one output row m and 4 consecutive output columns per accumulator quad -> 8-byte bf16x4 stores and
 // per-lane-contiguous fused epilogues (bias, per-image row vector, residuals, GEGLU).
+#include <stdlib.h>
+
 #include "common.h"
 #include "vista_hip.h"
 
 #include "gemm_common.h"
 
 namespace {
+
+// 128x160 two-per-CU tiles for DENSE LINEAR GEMMs with N <= K <= this. Same-box sweep (profiles/r03_tile5_sweep.txt): K = N = 320 projections
+// +20 % (0.305 -> 0.255 ms, 3.5 TB/s algorithmic), K = N = 640 +14 %, K = N = 1280 -7 %; N = 3K (q|k|v) -15 % and K = 4N (FF out) -3..-18 %: the
+// extra column tiles re-read the activations / the deep K-loop is MFMA-bound and wants the big tile.
+constexpr int TILE5_MAX_K_DEFAULT = 640;
 
 __device__ uint4 g_zero16;  // source of the zero fill for out-of-image conv taps on the LDS-DMA path (zero-initialised)
 
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         }
     }
     if constexpr (!OUT_F32 && EPI == EPI_LINEAR) {
-        if (eplan.fast) gemm_epilogue_linear_lds<FX, FY, FM, FN, BN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr, epi_vec, eplan.img0);
+        if (eplan.fast) gemm_epilogue_linear_lds<FX, FY, FM, FN, BN, (WM * WN == 16) ? 128 : 256>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr, epi_vec, eplan.img0);
         else gemm_epilogue<EPI, OUT_F32, FX, FY, FM, FN>(p, acc, m0, n0, wm, wn, l31, lh, tn * WN + wn, p.ln_stats != nullptr ? lnrow_cur : nullptr);
     } else if constexpr (EPI == EPI_GEGLU) {
         if (eplan.fast) gemm_epilogue_geglu_lds<FX, FY, FM, FN, BN>(p, acc, m0, n0, wm, wn, l31, lh, p.ln_stats != nullptr ? lnrow_cur : nullptr, epi_vec);
@@ -422,11 +429,16 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream, int ksplit = 1) {
 // rounding N up to 256 wastes > 10% of the MFMA work), 256x128, 128x128 -- but a variant is only taken if its grid covers the
 // chip (>= 192 workgroups, i.e. at least 3/4 of the CUs with one workgroup each; the 128x128 variant runs two per CU). Small-M problems (deep UNet levels, and every
 // level of a frame-sharded multi-GPU run) therefore fall back to smaller tiles instead of leaving CUs idle.
-struct TileChoice { int cfg, ksplit; };  // cfg: 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320
+struct TileChoice { int cfg, ksplit; };  // cfg: 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320, 5 = 128x160 (two workgroups per CU)
+
+// cfg 5 exists for DENSE / LINEAR / bf16-out GEMMs only (the HBM-bound K = C projections it is meant for): everything else maps it to 4
+inline bool cfg5_ok(const VkGemmDesc* d) { return d->amode == AMODE_DENSE && d->epi == EPI_LINEAR && !d->out_f32 && (d->N % 160) == 0; }
 inline TileChoice choose_tile(const VkGemmDesc* d) {
+    static const int tile5_max_k = [] { const char* e = getenv("VISTA_TILE5_MAXK"); return e ? atoi(e) : TILE5_MAX_K_DEFAULT; }();
     const int amode = d->amode, epi = d->epi;
     const int force = d->tile_cfg & 7;  // 0 = auto (tests / tuning force a variant)
     int cfg = force;
+    if (cfg == 5 && !cfg5_ok(d)) cfg = 4;
     if (cfg == 4 && amode == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
     if (cfg == 0) {
         auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
@@ -435,7 +447,12 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
         const bool ok320 = (epi != EPI_GEGLU) && (amode != AMODE_CONV3D) && (d->N % 320 == 0);
         const bool ok256 = n256 * 10 <= d->N * 11;
         const long long need = 192;  // >= 75 % of the 256 CUs in a single round still beats the smaller, less efficient tiles
-        if (ok320 && wgs(256, 320) >= need) cfg = 4;
+        // HBM-bound projections (K = C = N or thereabouts: under ~250 FLOP per byte of activations moved, against a ridge of 312): the
+        // 256x320 tile leaves ONE workgroup per CU whose DMA / MFMA / residual-read / store phases never overlap (2.9 TB/s algorithmic at
+        // K = N = 320, round 2). 128x160 tiles (81 KB of LDS) put TWO four-wave workgroups on a CU, out of phase with each other; the second
+        // column tile re-reads the activation rows from L2. Set VISTA_TILE5_MAXK (ops.py -> tile_cfg) to tune / disable.
+        if (cfg5_ok(d) && tile5_max_k > 0 && d->K <= tile5_max_k && d->N <= d->K && wgs(128, 160) >= 1024) cfg = 5;
+        else if (ok320 && wgs(256, 320) >= need) cfg = 4;
         else if (ok256 && wgs(256, 256) >= need) cfg = 3;
         else if (wgs(256, 128) >= need) cfg = 2;
         else cfg = 1;
@@ -463,7 +480,8 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
 
 // (block-tile width, wave columns) of a variant: the row-sum slabs of rowstat_out are one per (column tile, wave column)
 inline void tile_geometry(int cfg, int& bn, int& wn) {
-    if (cfg == 4) { bn = 320; wn = 2; }
+    if (cfg == 5) { bn = 160; wn = 1; }
+    else if (cfg == 4) { bn = 320; wn = 2; }
     else if (cfg == 3) { bn = 256; wn = 4; }
     else if (cfg == 2) { bn = 128; wn = 4; }
     else { bn = 128; wn = 2; }
@@ -472,6 +490,9 @@ inline void tile_geometry(int cfg, int& bn, int& wn) {
 template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
     const TileChoice t = choose_tile(d);
+    if constexpr (AMODE == AMODE_DENSE && EPI == EPI_LINEAR && !OUT_F32) {
+        if (t.cfg == 5) return launch_cfg<AMODE, EPI, OUT_F32, 4, 1, 1, 5>(d, stream);  // 128x160: four 32x160 wave tiles, two workgroups per CU
+    }
     if constexpr (AMODE != AMODE_CONV3D) {
         // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
         // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
@@ -486,7 +507,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 
 inline int validate(const VkGemmDesc* d) {
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 4 || d->tile_cfg > 7) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 5 || d->tile_cfg > 7) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;
