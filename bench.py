@@ -207,6 +207,7 @@ def main():
     ap.add_argument("--plumbing-only", action="store_true", help="N > 1: rendezvous + partition/exchange check on the host, no GPU work")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5, NOT the headline: FeedForward GEMMs AND the ResBlock convolutions in fp8 e4m3 (reported dtype says so)")
+    ap.add_argument("--fp8-no-attn", action="store_true", help="with --fp8: keep the attention score product and the attention-out projection in bf16 (the round-2 form)")
     ap.add_argument("--fp8-ff", action="store_true",
                     help="BASELINE config 5 experiment, NOT the headline: FeedForward GEMMs in fp8 e4m3 (reported dtype says so)")
     args = ap.parse_args()
@@ -241,6 +242,7 @@ def main():
         from vista_amd.modules import attention as _att
         _att.FP8["feedforward"] = True
         _att.FP8["conv"] = bool(args.fp8)
+        _att.FP8["attention"] = _att.FP8["proj"] = bool(args.fp8) and not args.fp8_no_attn
     from vista_amd import _lib, ops, synth
     from vista_amd.modules.diffusionmodules.denoiser import Denoiser
     from vista_amd.modules.diffusionmodules.sampling import EulerEDMSampler, FusedDenoiser, FusedLoop
@@ -349,7 +351,7 @@ def main():
     res = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ("bf16 + fp8(e4m3) FeedForward GEMMs and ResBlock convolutions [config 5]" if args.fp8 else
+        "dtype": (("bf16 + fp8(e4m3) FeedForward GEMMs, ResBlock convolutions" + ("" if args.fp8_no_attn else ", attention QK^T and attention-out projections") + " [config 5]") if args.fp8 else
                   "bf16 + fp8(e4m3) FeedForward GEMMs [config 5, FeedForward only]" if args.fp8_ff else "bf16"),
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (DRY RUN: gloo host-staged transport, ranks share one GPU -- not a result)",
         "config": {"workload": (f"{world}xMI355X " + layout(shard) +

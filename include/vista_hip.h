@@ -60,6 +60,14 @@ typedef struct VkGemmDesc {
     const float* rowvec2; /* f32 [M/rows_per_vec][ldv] or NULL, added with beta: out = alpha*(...) + beta*(res2 + rowvec2[row/rows_per_vec]) */
     int32_t act;         /* EPI_LINEAR: 0 = none; 1 = exact-erf GELU applied to (acc + bias + rowvec) BEFORE res1 / alpha -- the MLP of the
                             conditioner's OpenCLIP image tower: c_fc -> nn.GELU -> c_proj (vwm/modules/encoders/modules.py:273-279)           */
+    /* ---- BASELINE config 5: MX-fp8 output of the LEADING columns of a LINEAR GEMM (no quantisation pass): output columns [0, mx8_cols) are
+     *   written as e4m3 bytes to mx8_out[m][n] with one E8M0 scale per row and 32 columns in mx8_scales[m][n / 32] (2^e >= max|v| / 448,
+     *   chosen in the epilogue); columns n >= mx8_cols go to out[m][n - mx8_cols] (ldc counts `out`'s own columns). The q | k blocks of the fused
+     *   q|k|v projection feeding the fp8 QK^T of vk_attn_spatial_fp8qk (attention.py:344-346,391-407), and the FeedForward output feeding an
+     *   fp8 proj_out. N % 320 == 0, mx8_cols % 320 == 0, ld_mx8 % 16 == 0; bf16 out, no rowstat_out on those columns.                       */
+    void* mx8_out;
+    void* mx8_scales;
+    int32_t mx8_cols, ld_mx8, ld_mx8s;
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
@@ -154,6 +162,16 @@ int vk_attn_small_bf16(const void* qkv, void* o, int32_t n_img, int32_t heads, i
  * Only those columns are written: the caller zero-fills `out` (class-token row of every image, K padding) once. */
 int vk_clip_preprocess_patches(const float* img, void* out, int32_t n_img, int32_t H, int32_t W, int32_t out_hw, int32_t patch, int32_t ldo,
                                float sigma_y, float sigma_x, int32_t ks_y, int32_t ks_x, const float* mean3, const float* std3, void* stream);
+
+/* BASELINE config 5: the same attention with the score product in fp8. q8 / k8: e4m3 bytes, row (image*S + token) at q8 + row*ldq8 + head*64;
+ * q_scales / k_scales: E8M0 bytes, one per row and 32 head-dim elements, at + row*ldqs + 2*head + block -- the MX-fp8 q | k blocks written by the
+ * fused q|k|v projection's epilogue (VkGemmDesc.mx8_out). S^T = K . Q^T runs as v_mfma_scale_f32_32x32x64_f8f6f4 with both block scales applied
+ * inside the instruction; softmax, bf16 P and P.V on the bf16 V rows (v / ldv as in vk_attn_spatial_qkv_bf16) are unchanged.
+ * Output: bf16 `o` (ldo), or -- o8 != NULL -- MX fp8: e4m3 bytes at o8 + row*ldo8 + head*64 and E8M0 scales at o_scales + row*ldos + 2*head + block,
+ * which an fp8 attention-out projection consumes through VkFp8Args.a_mx (attention.py:391-421). */
+int vk_attn_spatial_fp8qk(const void* q8, const void* k8, const void* q_scales, const void* k_scales, const void* v, void* o, void* o8,
+                          void* o_scales, int32_t n_img, int32_t heads, int32_t S, int32_t ldq8, int32_t ldk8, int32_t ldqs, int32_t ldks,
+                          int32_t ldv, int32_t ldo, int32_t ldo8, int32_t ldos, float scale, void* stream);
 
 /* Temporal (cross-frame) self-attention over the T frames of every pixel: sequence length T <= 32, head dim 64.
  * Replaces the batchified xformers call at vwm/modules/attention.py:384-399 for VideoTransformerBlock.attn1

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 from vista_amd import ops
 n=50
 out={}
-for C,S,heads in ((320,9216,5),):
+for C,S,heads in ((320,9216,5),(640,2304,10),(1280,576,20)):
     g=torch.Generator(device="cuda").manual_seed(0)
     qkv=torch.randn(n*S,3*C,device="cuda",generator=g).to(torch.bfloat16)
     fn=lambda: ops.attn_spatial(qkv[:,:C],qkv[:,C:2*C],qkv[:,2*C:],n,heads,S,v_rows=True)
@@ -16,5 +16,5 @@ for C,S,heads in ((320,9216,5),):
         e1.record();torch.cuda.synchronize()
         best=min(best,e0.elapsed_time(e1)/5)
     out[f"S={S}"]=round(best,4)
-    out["TFLOPs"]=round(4.0*n*heads*S*S*64/best/1e9)
+    out[f"TFLOPs_S={S}"]=round(4.0*n*heads*S*S*64/best/1e9)
 print(json.dumps(out))

@@ -16,12 +16,10 @@ N = 50
 S = H * W
 M = N * S
 x = torch.randn(M, C, device="cuda").to(BF16)
-if kind == "attn":
-    pqk = ops.pack_linear_cat([torch.randn(C, C) * C ** -0.5, torch.randn(C, C) * C ** -0.5])
-    pv = ops.pack_linear(torch.randn(C, C) * C ** -0.5, None)
-    qk = ops.linear(x, pqk)
-    vt = ops.linear_vt(x, pv, S)
-    fn = lambda: ops.attn_spatial(qk[:, :C], qk[:, C:], vt, N, heads, S)  # noqa: E731
+if kind == "attn":  # the product form since round 3: q | k | v column blocks of ONE GEMM, V read row-major (ds_read_b64_tr_b16)
+    pqkv = ops.pack_linear_cat([torch.randn(C, C) * C ** -0.5 for _ in range(3)])
+    qkv = ops.linear(x, pqkv)
+    fn = lambda: ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], N, heads, S, v_rows=True)  # noqa: E731
 elif kind == "conv":
     pc = ops.pack_conv3x3(torch.randn(C, C, 3, 3) * (9 * C) ** -0.5, torch.randn(C))
     x3 = x.view(N, S, C)
@@ -33,9 +31,10 @@ elif kind == "ffout":
     h = torch.randn(M, 4 * C, device="cuda").to(BF16)
     po = ops.pack_linear(torch.randn(C, 4 * C) * (4 * C) ** -0.5, torch.randn(C))
     fn = lambda: ops.linear(h, po, res1=x)  # noqa: E731
-else:
+else:  # K = C projection with a residual (attention out / proj_out): the 128x160 two-per-CU tile at levels 0 / 1
     pw = ops.pack_linear(torch.randn(C, C) * C ** -0.5, torch.randn(C))
-    fn = lambda: ops.linear(x, pw)  # noqa: E731
+    res = torch.randn(M, C, device="cuda").to(BF16)
+    fn = lambda: ops.linear(x, pw, res1=res)  # noqa: E731
 for _ in range(3):
     fn()
 torch.cuda.synchronize()

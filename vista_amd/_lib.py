@@ -34,6 +34,7 @@ class VkGemmDesc(C.Structure):
         ("k_split", _i32), ("A2", _vp), ("lda2", _i32),
         ("ln_parts", _i32), ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_eps", _f32),
         ("rowstat_out", _vp), ("rowvec2", _vp), ("act", _i32),
+        ("mx8_out", _vp), ("mx8_scales", _vp), ("mx8_cols", _i32), ("ld_mx8", _i32), ("ld_mx8s", _i32),
     ]
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_spatial_qkv_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_attn_spatial_fp8qk": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_small_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_clip_preprocess_patches": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _vp],
     "vk_attn_temporal_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],

@@ -49,7 +49,32 @@ __device__ __forceinline__ bf16x8_t make_frag(uint2 a, uint2 b) {
     return __builtin_bit_cast(bf16x8_t, v);
 }
 
-__device__ uint4 g_attn_zero16;  // zero source for keys past the end of the sequence (LDS-DMA cannot predicate its write)
+__device__ uint4 g_attn_zero16;
+
+// MX-fp8 quantisation of one 32-element block held as four accumulator quads across the lane pair (l, l ^ 32): see mx_quant_block in gemm_common.h
+__device__ __forceinline__ uint4 mx_quant_block_attn(const float (&v)[4][4], int& e8m0) {
+    float amax = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[g][e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    int ex = -127;
+    if (amax > 0.f) frexpf(amax * (1.f / 448.f), &ex);
+    ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
+    const float inv = ldexpf(1.f, -ex);
+    uint32_t q[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(v[g][0] * inv, v[g][1] * inv, 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(v[g][2] * inv, v[g][3] * inv, w, true);
+        q[g] = (uint32_t)w;
+    }
+    const auto r02 = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
+    const auto r13 = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
+    e8m0 = ex + 127;
+    return make_uint4(r02[0], r02[1], r13[0], r13[1]);
+}  // zero source for keys past the end of the sequence (LDS-DMA cannot predicate its write)
 
 // actual key (within a 32-key subtile) held by K-tile LDS row rho: bits [g1 g0 h e1 e0] -> [g1 h g0 e1 e0].
 // With this row permutation the accumulator registers 8*(J&1)..+7 of lane-half h hold the 8 CONTIGUOUS keys 16J + 8h + 0..7,
@@ -542,6 +567,308 @@ extern "C" int vk_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, i
         return VK_EINVAL;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream_, x, (uint16_t*)y, cols, (long long)ldx,
                        (long long)ldy);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BASELINE config 5: spatial self-attention with the score MFMA in fp8 (vk_attn_spatial_fp8qk). Q and K arrive as e4m3 bytes with one E8M0
+// scale per row and 32 head-dim elements -- written by the fused q|k|v projection's epilogue (VkGemmDesc.mx8_out: no quantisation pass) --
+// and S^T = K . Q^T of a 32-key x 32-query block is ONE v_mfma_scale_f32_32x32x64_f8f6f4 (d = 64 = its K depth) with both operands' block
+// scales applied inside the instruction, instead of four bf16 32x32x16 MFMAs: a quarter of the score instructions at half their total time,
+// and a K tile of 4 KiB instead of 8. Softmax, bf16 P, and the PV product on the bf16 V rows are the bf16 kernel's (same fragments, same
+// key permutation); the output may leave as MX fp8 as well (o8 / os: the attention-out projection then runs as an fp8 GEMM with a_mx).
+// Operand layout of the scaled MFMA (probed in round 2, tools/probes/mx_scale_probe.hip): lane l holds row l & 31; VGPRs 0-3 = bytes
+// [16 lh, 16 lh + 16) of the row's first 32-byte K-block, VGPRs 4-7 = the same half of the second block; the E8M0 scale of (row r, block b)
+// is byte op_sel of the scale VGPR of lane r + 32 b, i.e. lane half lh supplies block lh.
+namespace {
+typedef __attribute__((ext_vector_type(8))) int i32x8a_t;
+
+template <int NW, int QW>
+__global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_kernel(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
+                                                                                      const uint8_t* __restrict__ qs, const uint8_t* __restrict__ ks,
+                                                                                      const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
+                                                                                      uint8_t* __restrict__ o8, uint8_t* __restrict__ os, int n_img, int heads,
+                                                                                      int S, int ldq8, int ldk8, int ldqs, int ldks, int ldv, int ldo, int ldo8,
+                                                                                      int ldos, float scale_log2, float rescale_thr) {
+    constexpr int QB = NW * QW * 32;
+    constexpr int GPW = 8 / NW;  // 8-row DMA groups of the V tile handled per wave
+    __shared__ __attribute__((aligned(16))) char smem[2 * 12288];  // per stage: K8 tile [64 keys][64 B] 4 KiB | V tile [64 keys][64 d] bf16 8 KiB
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int nqb = (S + QB - 1) / QB;
+    const int logical = xcd_remap(blockIdx.x, nqb * n_img * heads);
+    const int bh = logical / nqb, qb = logical - bh * nqb;
+    const int img = bh / heads, head = bh - img * heads;
+
+    // ---- Q fragments (B operand) and their block scales ----
+    int qrow[QW];
+    bool q_ok[QW];
+    i32x8a_t qf[QW];
+    int qsc[QW];
+#pragma unroll
+    for (int b = 0; b < QW; ++b) {
+        qrow[b] = qb * QB + (wave * QW + b) * 32 + l31;
+        q_ok[b] = qrow[b] < S;
+        if (!q_ok[b]) qrow[b] = S - 1;
+        const size_t row = (size_t)img * S + qrow[b];
+        const uint8_t* qp = q8 + row * ldq8 + head * 64 + 16 * lh;
+        const uint4 lo = *(const uint4*)qp, hi = *(const uint4*)(qp + 32);
+        qf[b][0] = lo.x; qf[b][1] = lo.y; qf[b][2] = lo.z; qf[b][3] = lo.w;
+        qf[b][4] = hi.x; qf[b][5] = hi.y; qf[b][6] = hi.z; qf[b][7] = hi.w;
+        qsc[b] = qs[row * ldqs + 2 * head + lh];
+    }
+
+    // ---- staging: K8 tile by waves 0-3 (16 rows x 64 B per LDS-DMA instruction), V tile as in the bf16 kernel (VROW form) ----
+    const int krho = 16 * (wave & 3) + (lane >> 2);                       // K8 LDS row filled by this lane
+    const int kchunk = (lane & 3) ^ ((krho >> 2) & 3);                    // logical 16-byte chunk it fetches (slot = chunk ^ ((row >> 2) & 3))
+    const int kkey = (krho & 32) + key_of_row(krho & 31);                 // key (within the tile) stored in that row
+    const uint32_t k_off = (uint32_t)(kkey * ldk8 + kchunk * 16);
+    const uint8_t* kbase = k8 + (size_t)img * S * ldk8 + head * 64;
+    const int dj = lane >> 3, dslot = lane & 7;
+    int v_row[GPW], v_chunk[GPW];
+    uint32_t v_off[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        v_row[i] = 8 * (wave + NW * i) + dj;
+        v_chunk[i] = dslot ^ (((v_row[i] >> 1) & 1) << 2);
+        v_off[i] = (uint32_t)(v_row[i] * ldv + v_chunk[i] * 8) * 2u;
+    }
+    const uint16_t* vbase = v + (size_t)img * S * ldv + head * 64;
+    const uint8_t* ksb = ks + (size_t)img * S * ldks + 2 * head + lh;     // + key * ldks: this lane half's block scale of a key
+    const bool ragged = (S & 63) != 0;
+    const int nt = (S + 63) >> 6;
+    auto dma_tile = [&](int t, int stage) __attribute__((always_inline)) {
+        const int key0 = t * 64;
+        char* sK = smem + stage * 12288;
+        char* sV = sK + 4096 + wave_u * 1024;
+        const bool last_ragged = ragged && t == nt - 1;
+        if (NW == 4 || wave_u < 4) {
+            const uint8_t* src = (!last_ragged || key0 + kkey < S) ? kbase + (size_t)key0 * ldk8 + k_off : (const uint8_t*)&g_attn_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sK + (wave_u & 3) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+            const uint16_t* src = (!last_ragged || key0 + v_row[i] < S) ? (const uint16_t*)((const char*)vbase + (size_t)key0 * ldv * 2 + v_off[i])
+                                                                         : (const uint16_t*)&g_attn_zero16;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sV + i * NW * 1024), 16, 0, 0);
+        }
+    };
+    // K block scales of tile t for this lane: key of accumulator-row l31 in each 32-key subtile (clamped past the end: those scores are masked)
+    auto k_scales = [&](int t, int (&out)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            int key = t * 64 + c * 32 + key_of_row(l31);
+            key = key < S ? key : S - 1;
+            out[c] = ksb[(size_t)key * ldks];
+        }
+    };
+
+    // fragment read offsets: K8 row l31 (+32 per subtile), chunks lh and 2 + lh under the 64-byte-row swizzle
+    const int ksw = (l31 >> 2) & 3;
+    const int kf_lo = l31 * 64 + ((lh ^ ksw) << 4), kf_hi = l31 * 64 + (((2 + lh) ^ ksw) << 4);
+    int vtr_base[2];
+    {
+        const int kq = (l31 & 15) >> 2, g1 = (l31 >> 4) & 1, c = l31 & 3, sw1 = (kq >> 1) & 1;
+        const int b0 = (8 * lh + kq) * 128 + (2 * g1 + (c >> 1)) * 16 + (c & 1) * 8;
+        vtr_base[0] = b0 + (0 ^ sw1) * 64;
+        vtr_base[1] = b0 + (1 ^ sw1) * 64;
+    }
+
+    f32x16_t oacc[QW][2];
+    float m_run[QW], l_run[QW];
+#pragma unroll
+    for (int b = 0; b < QW; ++b) {
+        m_run[b] = NEG_BIG;
+        l_run[b] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[b][d][r] = 0.f;
+    }
+    const float psum_limit = fast_exp2(fminf(rescale_thr, 100.f) + 5.f);
+    int ksc[2], ksc_next[2];
+    dma_tile(0, 0);
+    k_scales(0, ksc);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int stage = t & 1;
+        if (t + 1 < nt) { dma_tile(t + 1, stage ^ 1); k_scales(t + 1, ksc_next); }
+        const char* sK = smem + stage * 12288;
+        const char* sV = sK + 4096;
+
+        f32x16_t sacc[QW][2];
+        bf16x8_t pf[QW][4];
+        float psum[QW];
+        auto scores = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const uint4 lo = *(const uint4*)(sK + c * 32 * 64 + kf_lo), hi = *(const uint4*)(sK + c * 32 * 64 + kf_hi);
+                i32x8a_t kf;
+                kf[0] = lo.x; kf[1] = lo.y; kf[2] = lo.z; kf[3] = lo.w; kf[4] = hi.x; kf[5] = hi.y; kf[6] = hi.z; kf[7] = hi.w;
+#pragma unroll
+                for (int b = 0; b < QW; ++b) {
+                    f32x16_t z;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                    sacc[b][c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf[b], z, 0, 0, 0, ksc[c], 0, qsc[b]);
+                }
+            }
+            if (t == nt - 1 && (S & 63)) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = t * 64 + c * 32 + key_of_row((r & 3) + 8 * (r >> 2) + 4 * lh);
+                        if (key >= S) {
+#pragma unroll
+                            for (int b = 0; b < QW; ++b) sacc[b][c][r] = NEG_BIG;
+                        }
+                    }
+            }
+        };
+        auto probabilities = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < QW; ++b) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[b][c][r] = fast_exp2(fmaf(sacc[b][c][r], scale_log2, -m_run[b]));
+                psum[b] = 0.f;
+#pragma unroll
+                for (int J = 0; J < 4; ++J) {
+                    const int c = J >> 1, r0 = 8 * (J & 1);
+                    uint4 w;
+                    w.x = pack_bf16(sacc[b][c][r0 + 0], sacc[b][c][r0 + 1]);
+                    w.y = pack_bf16(sacc[b][c][r0 + 2], sacc[b][c][r0 + 3]);
+                    w.z = pack_bf16(sacc[b][c][r0 + 4], sacc[b][c][r0 + 5]);
+                    w.w = pack_bf16(sacc[b][c][r0 + 6], sacc[b][c][r0 + 7]);
+                    psum[b] = dot2_ones(w.x, psum[b]);
+                    psum[b] = dot2_ones(w.y, psum[b]);
+                    psum[b] = dot2_ones(w.z, psum[b]);
+                    psum[b] = dot2_ones(w.w, psum[b]);
+                    pf[b][J] = __builtin_bit_cast(bf16x8_t, w);
+                }
+            }
+        };
+        auto rebase = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int b = 0; b < QW; ++b) {
+                float mx = sacc[b][0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[b][0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][1][r]);
+                mx = fmaxf(pair_max(mx) * scale_log2, NEG_BIG);
+                const float m_new = fmaxf(m_run[b], mx);
+                const float alpha = fast_exp2(m_run[b] - m_new);
+                m_run[b] = m_new;
+                l_run[b] *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[b][d][r] *= alpha;
+            }
+        };
+        // the bf16 kernel's max-free fast path (see attn_spatial_kernel): exponentials against the existing base, validated by the row sums
+        scores();
+        if (__builtin_expect(t == 0, 0)) rebase();
+        probabilities();
+        bool bad = !(psum[0] <= psum_limit);
+#pragma unroll
+        for (int b = 1; b < QW; ++b) bad = bad || !(psum[b] <= psum_limit);
+        if (__builtin_expect(__any(bad), 0)) {
+            asm volatile("" ::: "memory");
+            scores();
+            rebase();
+            probabilities();
+        }
+#pragma unroll
+        for (int b = 0; b < QW; ++b) l_run[b] += psum[b];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+#pragma unroll
+            for (int J = 0; J < 4; ++J) {
+                typedef short s4_t __attribute__((ext_vector_type(4)));
+                typedef s4_t __attribute__((address_space(3))) * lds_s4_t;
+                const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sV + vtr_base[d] + J * 2048));
+                const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sV + vtr_base[d] + J * 2048 + 512));
+                bf16x8_t vf;
+                vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3]; vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+#pragma unroll
+                for (int b = 0; b < QW; ++b) oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][J], oacc[b][d], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        ksc[0] = ksc_next[0];
+        ksc[1] = ksc_next[1];
+    }
+
+#pragma unroll
+    for (int b = 0; b < QW; ++b) {
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        const float inv = 1.f / l_tot;
+        const size_t row = (size_t)img * S + qrow[b];
+        if (o8 != nullptr) {  // MX fp8 output: one E8M0 scale per row and 32 head-dim elements (= one accumulator set d)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                float vq[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vq[g][e] = oacc[b][d][4 * g + e] * inv;
+                int e8;
+                const uint4 q16 = mx_quant_block_attn(vq, e8);
+                if (q_ok[b]) {
+                    *(uint4*)(o8 + row * ldo8 + head * 64 + 32 * d + 16 * lh) = q16;
+                    if (lh == 0) {
+                        os[row * ldos + 2 * head + d] = (uint8_t)e8;
+                        if (d == 1 && head == heads - 1)  // pad bytes of the scale row (ldos is a multiple of 4 for the consumer GEMM's dword reads):
+                            for (int j = 2 * heads; j < ldos; ++j) os[row * ldos + j] = 127;  // 2^0 -- an uninitialised 0xFF would be an E8M0 NaN
+                    }
+                }
+            }
+        } else if (q_ok[b]) {
+            uint16_t* optr = o + row * ldo + head * 64 + 4 * lh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = pack_bf16(oacc[b][d][4 * g + 0] * inv, oacc[b][d][4 * g + 1] * inv);
+                    w.y = pack_bf16(oacc[b][d][4 * g + 2] * inv, oacc[b][d][4 * g + 3] * inv);
+                    *(uint2*)(optr + 32 * d + 8 * g) = w;
+                }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int vk_attn_spatial_fp8qk(const void* q8, const void* k8, const void* q_scales, const void* k_scales, const void* v, void* o, void* o8,
+                                     void* o_scales, int32_t n_img, int32_t heads, int32_t S, int32_t ldq8, int32_t ldk8, int32_t ldqs, int32_t ldks,
+                                     int32_t ldv, int32_t ldo, int32_t ldo8, int32_t ldos, float scale, void* stream_) {
+    if (!q8 || !k8 || !q_scales || !k_scales || !v || (!o && !o8) || (o8 && !o_scales) || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;
+    if ((S % 8) != 0 || (ldq8 % 16) != 0 || (ldk8 % 16) != 0 || (ldv % 8) != 0 || (o && (ldo % 4) != 0) || (o8 && (ldo8 % 16) != 0)) return VK_EINVAL;
+    if ((((size_t)q8) & 15) || (((size_t)k8) & 15) || (o8 && (((size_t)o8) & 15))) return VK_EINVAL;
+    static const float thr = [] { const char* e = getenv("VISTA_ATTN_RESCALE_THR"); return e ? (float)atof(e) : RESCALE_THR; }();
+    const int cls = S >= 4096 ? 2 : (S >= 2048 ? 1 : 0);
+    const int qb_rows = cls == 2 ? 512 : (cls == 1 ? 256 : 128);
+    const long long nblk = (long long)((S + qb_rows - 1) / qb_rows) * n_img * heads;
+    if (nblk > 0x7fffffffLL) return VK_EINVAL;
+#define FP8QK_LAUNCH(NW, QW)                                                                                                                    \
+    hipLaunchKernelGGL((attn_spatial_fp8qk_kernel<NW, QW>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint8_t*)q8,       \
+                       (const uint8_t*)k8, (const uint8_t*)q_scales, (const uint8_t*)k_scales, (const uint16_t*)v, (uint16_t*)o, (uint8_t*)o8,     \
+                       (uint8_t*)o_scales, n_img, heads, S, ldq8, ldk8, ldqs, ldks, ldv, ldo, ldo8, ldos, scale * LOG2E, thr)
+    if (cls == 2) FP8QK_LAUNCH(8, 2);
+    else if (cls == 1) FP8QK_LAUNCH(8, 1);
+    else FP8QK_LAUNCH(4, 1);
+#undef FP8QK_LAUNCH
     VK_CHECK_LAUNCH();
     return VK_OK;
 }

@@ -438,6 +438,7 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     const int amode = d->amode, epi = d->epi;
     const int force = d->tile_cfg & 7;  // 0 = auto (tests / tuning force a variant)
     int cfg = force;
+    if (d->mx8_out) cfg = 4;  // MX-fp8 output lives in the LDS-staged epilogue of whole 320-column tiles (validate() checked N and mx8_cols)
     if (cfg == 5 && !cfg5_ok(d)) cfg = 4;
     if (cfg == 4 && amode == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
     if (cfg == 0) {
@@ -520,6 +521,12 @@ inline int validate(const VkGemmDesc* d) {
     if (d->ln_stats && (d->amode != AMODE_DENSE || d->A2 || !d->ln_colsum || d->ln_parts <= 0 || d->ln_parts > 64 || !(d->ln_eps > 0.f))) return VK_EINVAL;
     if (d->rowstat_out && (d->epi != EPI_LINEAR || d->out_f32)) return VK_EINVAL;
     if (d->act != 0 && (d->act != 1 || d->epi != EPI_LINEAR)) return VK_EINVAL;
+    if (d->mx8_out && (!d->mx8_scales || d->epi != EPI_LINEAR || d->out_f32 || (d->N % 320) != 0 || d->mx8_cols <= 0 || (d->mx8_cols % 320) != 0 ||
+                       d->mx8_cols > d->N || (d->ld_mx8 % 16) != 0 || d->ld_mx8 < d->mx8_cols || d->ld_mx8s * 32 < d->mx8_cols ||
+                       (((size_t)d->mx8_out) & 15) != 0 || d->rowstat_out || (d->ldc % 8) != 0 || (((size_t)d->out) & 15) != 0 ||
+                       (d->amode != AMODE_DENSE) || d->res1 || d->res2 || d->rowvec || d->rowvec2 ||
+                       (unsigned long long)d->M * 2ull * (unsigned)d->ldc >= 0xfffff000ull))  // (what epi_plan needs to take the LDS-staged epilogue)
+        return VK_EINVAL;
     return VK_OK;
 }
 

@@ -34,6 +34,37 @@ __device__ __forceinline__ void unwiden_pair(const uint4& w, uint2& qa, uint2& q
     qb = make_uint2(rx[1], ry[1]);
 }
 
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+
+// MX-fp8 quantisation of ONE 32-column block of an output row held as the four accumulator quads of a 32x32 fragment: lane half lh holds
+// columns 8g + 4lh + e (g = quad, e = 0..3), i.e. 16 of the 32 values; its partner lane (l ^ 32) the others. Returns the lane's 16 bytes
+// of the block's 32 e4m3 bytes (to be stored at byte offset 16*lh of the block) and the block's E8M0 exponent byte (both lanes get it):
+// 2^(ex) >= max|v| / 448, the smallest such power of two (frexp), so every value lands in e4m3's range with at most one binade unused.
+__device__ __forceinline__ uint4 mx_quant_block(const float (&v)[4][4], int& e8m0) {
+    float amax = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fabsf(v[g][e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    int ex = -127;
+    if (amax > 0.f) frexpf(amax * (1.f / 448.f), &ex);  // amax/448 = f * 2^ex, f in [0.5, 1)
+    ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
+    const float inv = ldexpf(1.f, -ex);
+    uint32_t q[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) q[g] = pack_fp8x4(v[g][0] * inv, v[g][1] * inv, v[g][2] * inv, v[g][3] * inv);
+    // lower lane: [own q0 | partner q0 | own q1 | partner q1] = columns 0-15; upper lane: [partner q2 | own q2 | partner q3 | own q3] = 16-31
+    const auto r02 = __builtin_amdgcn_permlane32_swap(q[0], q[2], false, false);
+    const auto r13 = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
+    e8m0 = ex + 127;
+    return make_uint4(r02[0], r02[1], r13[0], r13[1]);
+}
+
 // LayerNorm fold (VkGemmDesc.ln_*): (mean, rstd) of activation row m from the producer's partial sums, summed in slab order. The GEMM
 // kernel evaluates this ONCE per tile row at kernel start (the HBM latency of the slab reads hides behind the first tile's DMA) and
 // parks the pairs in LDS; the epilogues read them back with ds_read -- reading the slabs from the epilogue itself exposed ~2 us of
@@ -357,7 +388,7 @@ __device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev
 // branch), because the sixteen-wave kernels live at the 128-VGPR cap with 64-80 accumulator registers: a residual that had to be spilled
 // would be WAITED for at the spill, which is exactly the serialisation this epilogue removes. Absent row vectors are staged as zeros and
 // added unconditionally (x + 0 is exact); the LayerNorm fold is a template flag (two more ds_reads and eight fmas per quad).
-template <int NRES, bool LN, int FX, int FY, int FM, int FN, int BN, int CAP>
+template <int NRES, bool LN, bool MX, int FX, int FY, int FM, int FN, int BN, int CAP>
 __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
                                                          int stat_part, const float2* lnrow, const float* ev, int img0) {
     constexpr int MW = FM * 32, NW = FN * 32, U = FX * FY;
@@ -365,6 +396,7 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
     // 128-VGPR cap, at 8 registers per unit and residual tensor
     constexpr int ROOM = (CAP - 16 * U - 36) / 8;  // CAP: the kernel's VGPR budget (128 for sixteen waves, 256 for eight)
     constexpr int DA = NRES == 0 ? 0 : ((ROOM / NRES < 1 ? 1 : ROOM / NRES) < U ? (ROOM / NRES < 1 ? 1 : ROOM / NRES) : U);
+    constexpr bool mx_tile = MX;  // this whole column tile is MX-fp8 output (the dispatcher checked n0 < mx8_cols; mx8_cols % BN == 0)
     const bool a_is_r1 = p.res1 != nullptr;  // slot a = res1 if there is one, else res2; slot b = res2 when both exist
     const uint16_t* __restrict__ ra = (const uint16_t*)(a_is_r1 ? p.res1 : p.res2);
     const uint16_t* __restrict__ rb = (const uint16_t*)p.res2;
@@ -382,7 +414,7 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
         mrow[fj] = row_ok[fj] ? m : p.M - 1;  // loads of a row past M read the last row; only the stores are predicated
         if (NRES >= 1) rao[fj] = ((uint32_t)mrow[fj] * (uint32_t)lda_ + (uint32_t)wide_off) * 2u;
         if (NRES == 2) rbo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ld_res2 + (uint32_t)wide_off) * 2u;
-        oo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ldc + (uint32_t)wide_off) * 2u;
+        oo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ldc + (uint32_t)(wide_off - (p.mx8_out ? p.mx8_cols : 0))) * 2u;  // (MX tiles never use it)
     }
     uint4 wa[U][2], wb[U][2];
     auto issue = [&](int fj, int fi, int u) {
@@ -448,10 +480,25 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
                 // residuals it was told to keep in flight
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const uint4 s0 = widen_pair(packed[0], packed[1]), s1 = widen_pair(packed[2], packed[3]);
-            if (row_ok[fj]) {
-                *(uint4*)(outb + oo[fj] + fi * 64) = s0;
-                *(uint4*)(outb + oo[fj] + fi * 64 + 32) = s1;
+            if constexpr (mx_tile) {
+                // BASELINE config 5: this column tile leaves as MX fp8 (the bf16 rounding above is what a bf16 consumer would have read; the
+                // e4m3 values are taken from it so that both output forms of a tile agree to fp8 precision)
+                float vq[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { vq[g][0] = bf16_lo(packed[g].x); vq[g][1] = bf16_hi(packed[g].x); vq[g][2] = bf16_lo(packed[g].y); vq[g][3] = bf16_hi(packed[g].y); }
+                int e8;
+                const uint4 q16 = mx_quant_block(vq, e8);
+                if (row_ok[fj]) {
+                    const int col = n0 + wn * NW + fi * 32;
+                    *(uint4*)((uint8_t*)p.mx8_out + (size_t)mrow[fj] * p.ld_mx8 + col + 16 * lh) = q16;
+                    if (lh == 0) ((uint8_t*)p.mx8_scales)[(size_t)mrow[fj] * p.ld_mx8s + (col >> 5)] = (uint8_t)e8;
+                }
+            } else {
+                const uint4 s0 = widen_pair(packed[0], packed[1]), s1 = widen_pair(packed[2], packed[3]);
+                if (row_ok[fj]) {
+                    *(uint4*)(outb + oo[fj] + fi * 64) = s0;
+                    *(uint4*)(outb + oo[fj] + fi * 64 + 32) = s1;
+                }
             }
             if (NRES >= 1 && u + DA < U) issue((u + DA) / FX, (u + DA) % FX, u + DA);  // this unit's residual registers are free again
             __builtin_amdgcn_sched_barrier(0);  // keep the order: this unit's stores, the next ring slot's loads, the next unit
@@ -467,7 +514,14 @@ template <int FX, int FY, int FM, int FN, int BN, int CAP = 128>
 __device__ __forceinline__ void gemm_epilogue_linear_lds(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
                                                          int stat_part, const float2* lnrow, const float* ev, int img0) {
     const int nres = (p.res1 != nullptr) + (p.res2 != nullptr);  // kernel-uniform
-#define VK_EPI_BODY(NR, LNF) epilogue_linear_lds_body<NR, LNF, FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0)
+    if constexpr (BN == 320) {  // MX-fp8 output tiles (BASELINE config 5; validate(): 320-column tiles, no residuals): their own instantiation,
+        if (p.mx8_out != nullptr && n0 < p.mx8_cols) {  // so that the bf16 bodies carry none of its registers
+            if (lnrow != nullptr) epilogue_linear_lds_body<0, true, true, FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0);
+            else epilogue_linear_lds_body<0, false, true, FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0);
+            return;
+        }
+    }
+#define VK_EPI_BODY(NR, LNF) epilogue_linear_lds_body<NR, LNF, false, FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0)
     if (lnrow != nullptr) {
         if (nres == 0) VK_EPI_BODY(0, true);
         else if (nres == 1) VK_EPI_BODY(1, true);

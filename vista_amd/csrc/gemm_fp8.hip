@@ -45,12 +45,6 @@ __device__ __forceinline__ uint4 widen_quads_fp8(uint32_t a_g0, uint32_t a_g1, u
     return make_uint4(r0[0], r0[1], r1[0], r1[1]);
 }
 
-__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
-    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-    return (uint32_t)v;
-}
-
 template <int AMODE, int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, int FN>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_fp8_kernel(const VkGemmDesc p, const F8Args q) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;

@@ -112,7 +112,11 @@ class GEGLU(nn.Module):
 # BASELINE config 5 opt-in (off by default; the headline path is bf16): run the FeedForward GEMMs -- GEGLU in-projection and
 # out-projection, 32 % of the UNet's FLOPs -- in fp8 e4m3 with per-token activation scales and per-channel weight scales.
 # "conv": additionally the ResBlock convolutions (2-D 3x3 and temporal 3x1x1) on e4m3 GroupNorm output (openaimodel.py ResBlock).
-FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1", "conv": os.environ.get("VISTA_FP8_CONV", "0") == "1"}
+# "attention": the spatial self-attention's score product in fp8 -- q | k leave the fused q|k|v projection's epilogue as MX fp8 (no pass) and
+# S^T = K Q^T is one scaled 32x32x64 fp8 MFMA per 32x32 block; "proj": additionally the attention output leaves the kernel as MX fp8 and the
+# attention-out projection (K = C) runs as an fp8 GEMM on it.
+FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1", "conv": os.environ.get("VISTA_FP8_CONV", "0") == "1",
+       "attention": os.environ.get("VISTA_FP8_ATTN", "0") == "1", "proj": os.environ.get("VISTA_FP8_PROJ", "0") == "1"}
 
 
 QKV_SPLIT = os.environ.get("VISTA_QKV_SPLIT", "0") == "1"  # A/B hook: spatial self-attention's projections as in round 2 (q|k + V^T GEMMs)
@@ -209,7 +213,10 @@ class MemoryEfficientCrossAttention(nn.Module, Packable):
 
     def _pack(self, dev):
         if self.is_self:
-            return {"out": ops.pack_linear(self.to_out[0].weight, self.to_out[0].bias, dev)}
+            pk = {"out": ops.pack_linear(self.to_out[0].weight, self.to_out[0].bias, dev)}
+            if FP8["proj"]:
+                pk["out8"] = ops.pack_linear_fp8(self.to_out[0].weight, self.to_out[0].bias, dev)
+            return pk
         w, b = self.context_map()
         return {"ctx": ops.pack_linear(w, b, dev)}
 
@@ -279,17 +286,33 @@ class BasicTransformerBlock(nn.Module, Packable):
         pk = self.packed()
         a1 = self.attn1.packed()
         C = self.dim
+        scale = self.attn1.dim_head ** -0.5
+        att8 = None
         if QKV_SPLIT:
             qk = ops.linear(x, pk["qk"], ln=stats)
             vt = ops.linear_vt(x, pk["v"], S, ln=stats)
-            att = ops.attn_spatial(qk[:, :C], qk[:, C:], vt, n_img, self.n_heads, S, self.attn1.dim_head ** -0.5)
+            att = ops.attn_spatial(qk[:, :C], qk[:, C:], vt, n_img, self.n_heads, S, scale)
+        elif FP8["attention"] and C % 320 == 0:
+            # BASELINE config 5: the same ONE GEMM, whose epilogue writes the q | k blocks as MX fp8 (e4m3 + a power-of-two scale per row and 32
+            # head-dim elements) and v as bf16; the score product runs in fp8 with the scales applied inside the MFMA. With "proj" the attention
+            # output leaves as MX fp8 too and the out-projection below is an fp8 GEMM -- no quantisation pass anywhere.
+            v, qk8, qks = ops.linear(x, pk["qkv"], ln=stats, mx8_cols=2 * C)
+            nb = C // 32
+            r8 = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], qks[:, :nb], qks[:, nb:], v, n_img, self.n_heads, S, scale, mx_out=FP8["proj"])
+            att8, att = (r8, None) if FP8["proj"] else (None, r8)
         else:
             # ONE q|k|v GEMM (attention.py:344-346), LayerNorm(norm1) folded: x is read once and never as a normalised copy; the attention
             # kernel takes V as the third column block and transposes its tiles on the way out of LDS (no V^T tensor, no TRANS GEMM)
             qkv = ops.linear(x, pk["qkv"], ln=stats)
-            att = ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_img, self.n_heads, S, self.attn1.dim_head ** -0.5, v_rows=True)
+            att = ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_img, self.n_heads, S, scale, v_rows=True)
         cv = self.attn2.context_vector(context)  # attn2(norm2(x), context): constant over the image's tokens
-        x, st = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=S, emit_stats=True)
+        if att8 is not None:
+            if "out8" not in a1:  # the switch was flipped after the bf16 pack was built
+                self.attn1.invalidate_packed()
+                a1 = self.attn1.packed()
+            x, st = ops.linear_fp8(att8[0], None, a1["out8"], a_mx=att8[1], res1=x, rowvec=cv, rows_per_vec=S, emit_stats=True)
+        else:
+            x, st = ops.linear(att, a1["out"], res1=x, rowvec=cv, rows_per_vec=S, emit_stats=True)
         r = self.ff.forward_folded(x, st, pk["ff_in"], self.norm3, res1=x, rowvec=out_rowvec, rows_per_vec=S, emit_stats=emit_stats)
         return r if emit_stats else (r, None)
 

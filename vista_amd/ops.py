@@ -247,7 +247,7 @@ def _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta,
 
 
 def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0, rowvec2=None,
-           x2=None, ln=None, emit_stats=False, act=None):
+           x2=None, ln=None, emit_stats=False, act=None, mx8_cols=0):
     """out = alpha*(act(X @ W^T + bias + rowvec[row // rows_per_vec]) + res1) + beta*(res2 + rowvec2[row // rows_per_vec]); act: None | "gelu".
     x: (..., K) bf16. x2: second source of a channel concat, X = [x | x2] (never materialised). ln: RowStats of x's rows when pw has
     a LayerNorm folded in (X = LayerNorm(x)). emit_stats: also return the RowStats of the (bf16) output -> (out, stats)."""
@@ -270,17 +270,27 @@ def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=
         if out is None:
             out = torch.empty((M, nout), dtype=BF16, device=x.device)
     elif out is None:
-        out = torch.empty((M, pw.N), dtype=F32 if out_f32 else BF16, device=x.device)
+        out = torch.empty((M, pw.N - mx8_cols), dtype=F32 if out_f32 else BF16, device=x.device)
     d.A, d.lda = _p(x2d), lda
     d.amode = AMODE_DENSE
     d.epi = EPI_GEGLU if pw.geglu else EPI_LINEAR
     _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta, rowvec2)
     _fill_ln(d, pw, ln, M)
+    mx = None
+    if mx8_cols:
+        # BASELINE config 5: the leading mx8_cols output columns leave as MX fp8 (e4m3 bytes + one E8M0 scale per row and 32 columns), the rest as
+        # bf16 into `out` (M, N - mx8_cols): the q | k blocks of the fused q|k|v projection for the fp8 QK^T (include/vista_hip.h, mx8_*)
+        if pw.geglu or emit_stats or mx8_cols % 320 or pw.N % 320 or out.shape[1] != pw.N - mx8_cols:
+            raise ValueError("linear: mx8_cols needs a LINEAR weight, N and mx8_cols multiples of 320, no emit_stats")
+        mx = (torch.empty((M, mx8_cols), dtype=torch.uint8, device=x.device), torch.empty((M, mx8_cols // 32), dtype=torch.uint8, device=x.device))
+        d.mx8_out, d.mx8_scales, d.mx8_cols, d.ld_mx8, d.ld_mx8s = _p(mx[0]), _p(mx[1]), mx8_cols, mx8_cols, mx8_cols // 32
     if act is not None:
         if act != "gelu" or pw.geglu:
             raise ValueError("linear: act must be None or 'gelu' (exact-erf GELU in the LINEAR epilogue)")
         d.act = 1
     stats = _gemm(d, emit_stats, x.device)
+    if mx is not None:
+        return out, mx[0], mx[1]
     return (out, stats) if emit_stats else out
 
 
@@ -587,8 +597,8 @@ def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_pe
     a = VkFp8Args()
     a.a_scale, a.w_scale, a.k_real = _p(a_scale), _p(pw.scale), K
     if a_mx is not None:
-        if a_mx.dtype != torch.uint8 or a_mx.shape != (M, K // 32) or not a_mx.is_contiguous():
-            raise ValueError("a_mx: contiguous uint8 (M, K/32) E8M0 block scales")
+        if a_mx.dtype != torch.uint8 or a_mx.dim() != 2 or a_mx.shape[0] != M or a_mx.shape[1] < K // 32 or a_mx.stride(1) != 1 or a_mx.stride(0) % 4:
+            raise ValueError("a_mx: uint8 (M, >= K/32) E8M0 block scales, row stride a multiple of 4 (the kernel reads one dword per 128 K-bytes)")
         a.a_mx, a.ld_mx = _p(a_mx), a_mx.stride(0)
     if mx_out:
         a.mx_out, a.ld_mx_out = _p(hs), hs.stride(0)
@@ -625,6 +635,36 @@ def attn_spatial(q, k, vt, n_img, heads, S, scale=None, v_rows=False):
         ev[1].record()
         PROFILE_ATTN.append((S, n_img * heads, ev[0], ev[1]))
     return o
+
+
+def attn_spatial_fp8qk(q8, k8, qs, ks, v, n_img, heads, S, scale=None, mx_out=False):
+    """BASELINE config 5: spatial self-attention with the score product in fp8. q8 / k8: (n_img*S, heads*64) uint8 views of e4m3 bytes (rows
+    may be strided: the q | k blocks of linear(..., mx8_cols=2C)); qs / ks: (n_img*S, 2*heads) uint8 views of their E8M0 block scales; v:
+    (n_img*S, heads*64) bf16 rows. Returns bf16 (n_img*S, heads*64), or with mx_out=True (o8 uint8 (M, C), o_scales uint8 (M, C/32))."""
+    _need(v, BF16, "v")
+    for name, t in (("q8", q8), ("k8", k8), ("qs", qs), ("ks", ks)):
+        if t.dtype != torch.uint8 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+            raise TypeError(f"attn_spatial_fp8qk: {name} must be a 2-D uint8 device view with contiguous rows")
+    M, c = n_img * S, heads * 64
+    if q8.shape != (M, c) or k8.shape != (M, c) or qs.shape != (M, 2 * heads) or ks.shape != (M, 2 * heads) or v.shape != (M, c) or v.stride(1) != 1:
+        raise ValueError("attn_spatial_fp8qk: shape mismatch")
+    o = o8 = osc = None
+    if mx_out:
+        o8 = torch.empty((M, c), dtype=torch.uint8, device=v.device)
+        osc = torch.empty((M, ceil_to(2 * heads, 4)), dtype=torch.uint8, device=v.device)  # row stride % 4 for the consumer GEMM; the kernel sets the pad bytes to 2^0
+    else:
+        o = torch.empty((M, c), dtype=BF16, device=v.device)
+    ev = None
+    if PROFILE_ATTN is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    check(_lib.load().vk_attn_spatial_fp8qk(_p(q8), _p(k8), _p(qs), _p(ks), _p(v), _p(o), _p(o8), _p(osc), n_img, heads, S, q8.stride(0), k8.stride(0),
+                                            qs.stride(0), ks.stride(0), v.stride(0), c, c, ceil_to(2 * heads, 4),
+                                            float(scale if scale is not None else 1.0 / math.sqrt(64)), _stream()), "vk_attn_spatial_fp8qk")
+    if ev is not None:
+        ev[1].record()
+        PROFILE_ATTN.append((S, n_img * heads, ev[0], ev[1]))
+    return (o8, osc) if mx_out else o
 
 
 def attn_small(qkv, n_img, heads, S, D, scale=None):
