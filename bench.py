@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--shard", choices=["hybrid", "frames"], default="hybrid")
     ap.add_argument("--cpu-sample", type=str, default="16x32")
     ap.add_argument("--plumbing-only", action="store_true", help="N > 1: rendezvous + partition/exchange check on the host, no GPU work")
+    ap.add_argument("--graph", action="store_true", help="replay every step's UNet forward from one captured hipGraph (FusedLoop(graph=True)); the "
+                    "level-0 attention launches of the roofline object are then timed on one extra eager step outside the timed region")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5, NOT the headline: FeedForward GEMMs AND the ResBlock convolutions in fp8 e4m3 (reported dtype says so)")
     ap.add_argument("--fp8-no-attn", action="store_true", help="with --fp8: keep the attention score product and the attention-out projection in bf16 (the round-2 form)")
@@ -283,9 +285,10 @@ def main():
     assert args.warmup + args.steps <= nsteps, "at most 50 steps per window"
     fd = FusedDenoiser(den, OpenAIWrapper(net))
 
-    def timed_loop(shard, profile_attn):
+    def timed_loop(shard, profile_attn, graph=False):
         """W warm-up + K timed steps of a fresh window; returns (seconds for K steps = MAX over ranks, host enqueue seconds, loop)."""
-        loop = FusedLoop(sampler, fd, x.float().clone(), cond, uc, w["cond_frame"].cuda(), w["cond_mask"].cuda(), True, sig, shard=shard)
+        loop = FusedLoop(sampler, fd, x.float().clone(), cond, uc, w["cond_frame"].cuda(), w["cond_mask"].cuda(), True, sig, shard=shard,
+                         graph=graph)
         for i in range(args.warmup):
             loop.step(i)
         torch.cuda.synchronize()
@@ -323,7 +326,14 @@ def main():
 
     main_key = args.shard if world > 1 else None
     shard = shards[main_key]
-    dt, t_enqueue, _ = timed_loop(shard, True)
+    dt, t_enqueue, _ = timed_loop(shard, not args.graph, graph=args.graph)
+    if args.graph:  # a replayed graph runs no Python between launches: time the roofline kernel's launches on one eager step of the same state
+        eager = FusedLoop(sampler, fd, x.float().clone(), cond, uc, w["cond_frame"].cuda(), w["cond_mask"].cuda(), True, sig, shard=shard, graph=False)
+        eager.step(0)
+        torch.cuda.synchronize()
+        ops.PROFILE_ATTN = []
+        eager.step(1)
+        torch.cuda.synchronize()
     prof, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None
     ms_per_step = dt * 1e3 / args.steps
     value = args.steps / dt
@@ -366,6 +376,7 @@ def main():
                     f"frame-shard x{shard.P} (spatial half) + pixel-shard x{shard.P} (temporal half), 2 RCCL all-to-alls per block pair, "
                     "weights replicated")},
         "roofline": roofline,
+        "hipgraph": bool(args.graph),
         "host_enqueue_ms_idle_stream": None if t_enqueue is None else t_enqueue * 1e3,  # one step enqueued after a sync, outside the timed region
         "step_mfma_frac": (FLOP_PER_STEP_CFG / (ms_per_step * 1e-3) / (MFMA_BF16_PEAK * world)) if full else None,
     }

@@ -36,7 +36,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--mode", default="hybrid")
     ap.add_argument("--cprofile", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the UNet forward from one captured hipGraph (VISTA_HIPGRAPH=force: the mock collectives are plain kernels)")
+    ap.add_argument("--torch-profile", action="store_true", help="per-kernel table of the timed steps only (no model-build / packing kernels)")
     a = ap.parse_args()
+    if a.graph:
+        os.environ["VISTA_HIPGRAPH"] = "force"
     import bench
     from vista_amd import synth
     from vista_amd.modules.diffusionmodules.denoiser import Denoiser
@@ -68,6 +72,18 @@ def main():
         pr.disable()
         torch.cuda.synchronize()
         pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+        return
+    if a.torch_profile:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for i in range(1, 1 + a.steps):
+                loop.step(i)
+            torch.cuda.synchronize()
+        rows = sorted(((e.key, e.count, e.device_time_total) for e in prof.key_averages() if e.device_time_total > 0), key=lambda r: -r[2])
+        tot = sum(r[2] for r in rows)
+        print(f"# {a.steps} steps, world {a.world} mode {a.mode}: kernel time {tot / 1e3 / a.steps:.2f} ms/step, {sum(r[1] for r in rows) / a.steps:.0f} launches/step")
+        for k, c, t in rows[:60]:
+            print(f"{t / 1e3 / a.steps:8.3f} ms/step {c / a.steps:7.1f} calls/step  avg {t / c:8.1f} us  {k[:140]}")
         return
     t0 = time.perf_counter()
     for i in range(1, 1 + a.steps):

@@ -130,9 +130,16 @@ class FusedLoop:
     """State of one fused sampling run; `step(i)` is exactly one EulerEDMSampler.sampler_step (sampling.py:78-89):
     mask replace -> CFG-doubled UNet forward -> guider combine -> to_d -> Euler update. bench.py times this."""
 
-    def __init__(self, sampler, fd, xw, cond, uc, cond_frame, maskf, replace, sig, shard=None):
+    def __init__(self, sampler, fd, xw, cond, uc, cond_frame, maskf, replace, sig, shard=None, graph=None):
         from .video_model import CIN_PAD
         self.cin_pad = CIN_PAD
+        # graph: replay the UNet forward of every step from ONE captured hipGraph (the ~800 launches of a step become one host call; the
+        # per-step scalars live in the sampler kernels outside it, the noise level enters through a device tensor). Default: env VISTA_HIPGRAPH=1.
+        # Off whenever the forward contains collectives (frame-sharded groups): capturing RCCL is left opt-in (VISTA_HIPGRAPH=force).
+        import os
+        want = os.environ.get("VISTA_HIPGRAPH", "0") if graph is None else ("1" if graph else "0")
+        self._graph_mode = want
+        self._graph = None
         self.den, self.unet = fd.denoiser, fd.network.diffusion_model
         self.sig, self.replace, self.shard = sig, replace, shard
         n, _, self.H, self.W = xw.shape
@@ -165,17 +172,39 @@ class FusedLoop:
         # EDM coefficients per step on the host (denoiser_scaling.py:51-59): no device round trip inside the loop
         self.coef = [tuple(float(v) for v in self.den.scaling(torch.tensor(s, dtype=torch.float32))) for s in sig[:-1]]
 
+    def _unet(self, net_in, n_ts, c_noise):
+        """One UNet forward on the step's input; eager, or the replay of the captured graph (same kernels, same buffers every step)."""
+        use = self._graph_mode == "force" or (self._graph_mode == "1" and self.unet_shard is None)
+        if not use:
+            ts = torch.full((n_ts,), c_noise, device=self.xw.device)
+            return self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.unet_shard)
+        g = self._graph
+        if g is None:
+            g = self._graph = {"in": torch.empty_like(net_in), "ts": torch.empty((n_ts,), device=self.xw.device)}
+            g["in"].copy_(net_in)
+            g["ts"].fill_(c_noise)
+            fwd = lambda: self.unet.forward_tokens(g["in"], g["ts"], self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.unet_shard)  # noqa: E731
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):   # eager warm-up off the capture: weight packs, workspaces and caches get built here
+                fwd()
+            torch.cuda.current_stream().wait_stream(side)
+            g["graph"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["graph"]):
+                g["out"] = fwd()
+        g["in"].copy_(net_in)
+        g["ts"].fill_(c_noise)
+        g["graph"].replay()
+        return g["out"]
+
     def step(self, i):
         c_skip, c_out, c_in, c_noise = self.coef[i]
         net_in = ops.sampler_prepare(self.xw, self.cf, self.maskf, self.cu, self.cc, self.cin_pad, c_in, self.replace)
         if self.half is None:
-            ts = torch.full((2 * self.n,), c_noise, device=self.xw.device)
-            net_out = self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.unet_shard)
+            net_out = self._unet(net_in, 2 * self.n, c_noise)
         else:  # run this rank's guidance half, then swap outputs with the partner that owns the same frames of the other half
             tl = self.xw.shape[0]
-            ts = torch.full((self.n,), c_noise, device=self.xw.device)
-            mine = self.unet.forward_tokens(net_in[self.half * tl:(self.half + 1) * tl], ts, self.ctx2, self.y2, self.mask2, self.T,
-                                            self.H, self.W, shard=self.unet_shard)
+            mine = self._unet(net_in[self.half * tl:(self.half + 1) * tl], self.n, c_noise)
             net_out = self.shard.exchange_cfg_halves(mine)
         ops.sampler_update(self.xw, net_out, self.scales, c_out, c_skip, self.sig[i], self.sig[i + 1])
 
