@@ -203,3 +203,31 @@ def test_downsample_upsample_outconv_at_baseline_shape():
     h = ops.groupnorm(_tok(x), gw.cuda(), gb.cuda(), 1e-5, silu=True)
     out, _, _ = ops.conv3x3(h, ops.pack_conv3x3(cw, cb), n, 72, 128, out_f32=True)
     _report("out: GN32+SiLU+conv3x3 320->4 @72x128", _nchw(out[:, :, :4], n, 72, 128), ref, 5e-3, 2e-2, t_ref)
+
+
+def test_frame_position_rows_are_reused_only_for_the_same_unchanged_frame_index_tensor():
+    """SpatialVideoTransformer keeps time_pos_embed(sinusoid(frame_idx)) next to its packed weights while the caller passes the SAME frame_idx
+    tensor unchanged: the cached forward equals the uncached one bit for bit, an in-place change of the indices (version counter) or a
+    changed time_pos_embed weight recomputes them."""
+    from vista_amd import ops
+    from vista_amd.modules.video_attention import SpatialVideoTransformer
+    T, C, H, W = 3, 64, 4, 8
+    blk = SpatialVideoTransformer(C, 1, 64, depth=1, context_dim=1024, use_linear=True, use_spatial_context=True, ff_in=True,
+                                  merge_strategy="learned_with_images", merge_factor=0.5, attn_mode="softmax-xformers", action_control=False)
+    _seed(blk, "blk", 11)
+    blk = blk.cuda().eval()
+    x = _tok(_rand((T, C, H, W), 3))
+    ctx = ops.cast_to_bf16(_rand((T, 1024), 4).cuda())
+    fi = torch.arange(T, dtype=torch.float32).cuda()
+    with torch.no_grad():
+        first = blk(x, ctx, fi, T, H, W)                       # fills the cache
+        assert blk.packed()["_tpe_rows"][0] is fi
+        again = blk(x, ctx, fi, T, H, W)                       # served from it
+        fresh = blk(x, ctx, fi.clone(), T, H, W)               # another tensor object: recomputed
+        assert torch.equal(first, again) and torch.equal(first, fresh)
+        fi.add_(2.0)                                           # same object, new contents
+        moved = blk(x, ctx, fi, T, H, W)
+        assert not torch.equal(moved, first) and torch.equal(moved, blk(x, ctx, fi.clone(), T, H, W))
+        blk.time_pos_embed[2].bias.add_(0.5)                   # a weight change drops the pack and the rows with it
+        rew = blk(x, ctx, fi, T, H, W)
+        assert not torch.equal(rew, moved) and torch.equal(rew, blk(x, ctx, fi.clone(), T, H, W))

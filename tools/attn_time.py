@@ -1,7 +1,7 @@
 import os, sys, json, torch
 sys.path.insert(0, os.getcwd())
 from vista_amd import ops
-n=50
+n=int(sys.argv[1]) if len(sys.argv)>1 else 50
 out={}
 for C,S,heads in ((320,9216,5),(640,2304,10),(1280,576,20)):
     g=torch.Generator(device="cuda").manual_seed(0)

@@ -32,7 +32,8 @@ def timeit(fn, iters=10):
 
 def main():
     flags = [int(v) for v in (sys.argv[1].split(",") if len(sys.argv) > 1 else "0".split(","))]  # values of ops.TILE_CFG to compare (0 = the launcher's own choice; 1..5 force a block tile)
-    N = 50
+    N = int(os.environ.get("SWEEP_IMAGES", "50"))  # 50 = the CFG-doubled 25-frame window; 7 / 8 = one rank of an 8-GPU run
+    T = 25 if N % 25 == 0 else N
     rn = lambda *s: torch.randn(*s, device="cuda")  # noqa: E731
     for C, H, W in ((320, 72, 128), (640, 36, 64), (1280, 18, 32)):
         M = N * H * W
@@ -57,7 +58,7 @@ def main():
                 h4, pw, res1=res, alpha=0.4, res2=x, rowvec2=rv, beta=0.6, rows_per_vec=H * W), 2.0 * M * 4 * C * C),
             "attn_out+ctx": (lambda pw=ops.pack_linear(rn(C, C) * C ** -0.5, rn(C)), rv=rn(N, C): ops.linear(
                 x, pw, res1=res, rowvec=rv, rows_per_vec=H * W, emit_stats=True), 2.0 * M * C * C),
-            "conv_t3": (lambda pw=ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C)): ops.conv_t3(x3, pw, 25, H * W), 2.0 * M * 3 * C * C),
+            "conv_t3": (lambda pw=ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C)): ops.conv_t3(x3, pw, T, H * W), 2.0 * M * 3 * C * C),
         }
         for name, (fn, flop) in cases.items():
             best = {}

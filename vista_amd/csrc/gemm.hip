@@ -457,13 +457,34 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
         else if (ok256 && wgs(256, 256) >= need) cfg = 3;
         else if (wgs(256, 128) >= need) cfg = 2;
         else cfg = 1;
+        // Round-aware corrections for SMALL problems (one rank of a frame-sharded run: 7-8 images instead of 50; the deepest level of the
+        // full problem). Same-box sweep at 7 images, all five tiles forced in turn (profiles/r03_gemm_sweep_rank7.jsonl):
+        //  * GEGLU walks its tile list with 256 persistent workgroups, so its time is ceil(tiles / 256) tile-times: 4032 x 10240 x 1280 is
+        //    640 tiles of 256x256 = 3 rounds but 512 tiles of 256x320 = exactly 2 (126 -> 108 us); the wider tile is ~5 % slower per
+        //    FLOP (the 2-9 % measured at full size, where the rounds are 18 / 36 / 71 and the rule keeps 256x256).
+        if (epi == EPI_GEGLU && amode == AMODE_DENSE && (d->N % 320) == 0 && cfg == 3) {
+            const long long r3 = (wgs(256, 256) + 255) / 256, r4 = (wgs(256, 320) + 255) / 256;
+            if (r4 * 320 * 100 < r3 * 256 * 95) cfg = 4;
+        }
+        //  * DENSE LINEAR: when the tile picked above fills < 75 % of its last round (e.g. 16128 x 640: 126 tiles of 256x320 do not reach
+        //    `need`, 315 of 256x128 are 1.23 rounds), 128x160 tiles -- two co-resident workgroups per CU, which degrade gracefully in a
+        //    partial round -- were 16-34 % faster on every K (640 .. 5120), including the K = 4N FeedForward out-projections that prefer
+        //    the big tile at full size. Needs >= 192 of them; smaller problems are left to the split-K rule below.
+        if (cfg5_ok(d) && cfg != 5 && tile5_max_k > 0 && wgs(128, 160) >= need) {
+            int bm = 256, bn = 320, slots = 256;
+            if (cfg == 3) bn = 256;
+            else if (cfg == 2) bn = 128;
+            else if (cfg == 1) { bm = 128; bn = 128; slots = 512; }
+            const long long w = wgs(bm, bn), rounds = (w + slots - 1) / slots;
+            if (w * 100 < rounds * slots * 75) cfg = 5;
+        }
     }
     // Split-K for small-M, deep-K problems (deep UNet levels; every level of a frame-sharded multi-GPU rank): when even the
     // 128-wide tiles would leave the chip under-filled or ragged, run the LARGEST tile over 2..8 K slices instead, so that
     // tiles x slices ~ one full round of CUs; fp32 partials go to the caller's workspace and a finishing pass applies the epilogue.
     // Not combined with the LayerNorm fold / row-sum emission (their epilogues need the finished accumulator in registers).
     int ksplit = 1;
-    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && !d->ln_stats && !d->rowstat_out && !d->act) {
+    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && cfg != 5 && !d->ln_stats && !d->rowstat_out && !d->act) {
         const bool ok320s = (amode != AMODE_CONV3D) && (d->N % 320 == 0);
         const int bn = ok320s ? 320 : 256;
         const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
