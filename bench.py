@@ -410,6 +410,21 @@ def main():
                                           "note": "IdentityGuider: one UNet forward on N=25 images per step (half the CFG work), generic sampler path"}
             if full:
                 res["roofline_gemm"] = gemm_rooflines(ops, 2 * T, H, W)
+            if full and not (args.fp8 or args.fp8_ff):
+                # BASELINE config 5 as a side figure of the default (bf16) line: the same step with FeedForward GEMMs, ResBlock convolutions, the
+                # attention score product and the attention-out projection in fp8 e4m3; the fp8 weight packs are built during the
+                # warm-up steps. Not the headline: `value` above stays bf16.
+                from vista_amd.modules import attention as _att
+                saved = dict(_att.FP8)
+                try:
+                    for k in ("feedforward", "conv", "attention", "proj"):
+                        _att.FP8[k] = True
+                    dt8, _, _ = timed_loop(None, False)
+                    res["config5_fp8"] = {"value": args.steps / dt8, "unit": "steps/s", "ms_per_step": dt8 * 1e3 / args.steps,
+                                          "note": "same step, fp8(e4m3) FeedForward GEMMs, ResBlock convolutions, attention QK^T and attention-out projections; "
+                                                  "parity: tests/test_fp8_gpu.py, tests/test_blocks_gpu.py"}
+                finally:
+                    _att.FP8.update(saved)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         h, wd = (int(v) for v in args.cpu_sample.split("x"))
         res["cpu_baseline"] = cpu_baseline(net, T, (h, wd), seed=1)
