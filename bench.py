@@ -347,13 +347,13 @@ def main():
         avg_ms = sum(l0) / len(l0)
         flop = 4.0 * nbh * float(H * W) ** 2 * 64
         ach = flop / (avg_ms * 1e-3) / 1e12
-        traffic = None  # HBM bytes per launch from the separate PMC passes (profiles/r02_attn_traffic.json), full config only
-        tp = os.path.join(ROOT, "profiles", "r02_attn_traffic.json")
+        traffic = None  # HBM bytes per launch from the separate PMC passes (profiles/r03_attn_traffic.json), full config only
+        tp = os.path.join(ROOT, "profiles", "r03_attn_traffic.json")
         if full and world == 1 and os.path.exists(tp):
             traffic = json.load(open(tp))["traffic_bytes_per_launch"]
         roofline = {"kernel": "attn_spatial_kernel (level-0 spatial self-attention)", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": traffic,
-                    "traffic_source": "rocprofv3 PMC passes of the same kernel and shape, profiles/r02_attn_traffic.json (PMC passes cannot share a run with the timed region)",
+                    "traffic_source": "rocprofv3 PMC passes of the same kernel and shape, profiles/r03_attn_traffic.json (PMC passes cannot share a run with the timed region)",
                     "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop}
 
     def layout(sh):
