@@ -147,6 +147,13 @@ int vk_attn_spatial_bf16(const void* q, const void* k, const void* vt, void* o, 
 int vk_attn_spatial_qkv_bf16(const void* q, const void* k, const void* v, void* o, int32_t n_img, int32_t heads,
                              int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream);
 
+/* The same attention for a query that ALREADY carries softmax_scale * log2(e) -- folded into the to_q weight rows when they are packed
+ * (vwm/modules/attention.py:344,400-407: q = to_q(x), scale = dim_head ** -0.5; one bf16 rounding of the scaled projection instead of one of the
+ * unscaled one: no extra error). q . k is then the base-2 exponent itself; rows whose running maximum lies within +-60 octaves use the base 0
+ * (P = exp2(q . k), no per-score scale / base arithmetic), others re-base on their true maximum exactly like vk_attn_spatial_qkv_bf16. */
+int vk_attn_spatial_qkv_log2_bf16(const void* q, const void* k, const void* v, void* o, int32_t n_img, int32_t heads,
+                                  int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, void* stream);
+
 /* Small dense attention, any head dim D in {64, 80, 128}: softmax(q k^T * scale) v per (image, head); q / k / v are column blocks of one
  * row-major buffer (q at qkv + row*ld + head*D, k at + k_off, v at + v_off; row = image*S + token). The nn.MultiheadAttention of the
  * conditioner's OpenCLIP ViT-H/14 image tower (FrozenOpenCLIPImageEmbedder, vwm/modules/encoders/modules.py:251-399: 257 tokens, 16 heads

@@ -230,6 +230,54 @@ def test_attn_spatial_qkv_rows(n_img, heads, S):
         ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], vt, n_img, heads, S, v_rows=True)   # a V^T tensor passed as rows
 
 
+@pytest.mark.parametrize("n_img,heads,S", [(2, 5, 144), (1, 2, 576), (1, 5, 2304), (2, 3, 200), (1, 1, 9216), (2, 1, 2120), (1, 3, 4104)])
+def test_attn_spatial_qkv_log2_prescaled_query(n_img, heads, S):
+    """The pre-scaled form (vk_attn_spatial_qkv_log2_bf16): the query weights carry dim_head^-0.5 * log2(e), a score is the base-2 exponent
+    and rows with a maximum within +-60 octaves run against the base ZERO (no scale / base arithmetic per score). Against fp32 SDPA of the
+    scaled projection the kernel actually saw, and against the plain kernel on the unscaled one."""
+    ops = _ops()
+    Cc = heads * 64
+    x = rnd(n_img * S, Cc, scale=1.0)
+    wq, wk, wv = (rnd(Cc, Cc, scale=1.5 * Cc ** -0.5, seed=s) for s in (1, 2, 3))
+    c = 64 ** -0.5 * ops.LOG2E
+    qkv = ops.linear(x, ops.pack_linear_cat([wq, wk, wv]))
+    qkv2 = ops.linear(x, ops.pack_linear_cat([wq.float() * c, wk, wv]))
+    assert torch.equal(qkv[:, Cc:], qkv2[:, Cc:])
+    o = ops.attn_spatial(qkv2[:, :Cc], qkv2[:, Cc:2 * Cc], qkv2[:, 2 * Cc:], n_img, heads, S, v_rows=True, q_log2=True)
+    q, k, v = (qkv2[:, i * Cc:(i + 1) * Cc].float().view(n_img, S, heads, 64).permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / ops.LOG2E, -1) @ v).permute(0, 2, 1, 3).reshape(n_img * S, Cc)   # exp2(q.k) = exp(q.k ln 2)
+    close(o, ref, f"attn_spatial log2-prescaled q S={S}", rtol=2e-2, arel=3e-2)
+    # against the plain kernel on the UNSCALED projection the two differ by which bf16 rounding of q they saw (one each, of the same fp32
+    # value): relative L2 ~5e-3 on these unit-variance logits, i.e. the projection's own rounding noise, not the kernel's
+    plain = ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], n_img, heads, S, v_rows=True).float()
+    assert ((o.float() - plain).pow(2).sum() / plain.pow(2).sum()).sqrt().item() < 1.2e-2
+    assert torch.equal(o, ops.attn_spatial(qkv2[:, :Cc], qkv2[:, Cc:2 * Cc], qkv2[:, 2 * Cc:], n_img, heads, S, v_rows=True, q_log2=True))
+
+
+@pytest.mark.parametrize("S", [512, 4608])
+@pytest.mark.parametrize("gain", [3.0, 12.0, 60.0, 400.0])
+def test_attn_spatial_qkv_log2_leaves_the_zero_base_when_it_must(S, gain):
+    """Zero-base edge cases of the pre-scaled kernel: exponents far above +60 (gain 12: ~140 octaves -> exp2 overflows to +inf against base 0,
+    the row-sum test fails and the row re-bases on its true maximum), a row whose FIRST tile lies far below -60 (true first base), spikes
+    that arrive in late tiles, an all-equal row, and rows that stay inside the band (gain 3 on most rows)."""
+    ops = _ops()
+    c = 64 ** -0.5 * ops.LOG2E
+    q = rnd(S, 64)
+    k = rnd(S, 64, seed=1)
+    v = rnd(S, 64, seed=2)
+    for j, row in enumerate(range(70, S, 197)):
+        k[row] = q[(37 * j + 5) % S] * gain
+    k[:64] = -q[300] * gain
+    k[S - 1] = q[300] * gain
+    q[11] = 0
+    qs = (q.float() * c).to(BF16)
+    buf = torch.cat([qs, k, v], 1).contiguous()
+    o = ops.attn_spatial(buf[:, :64], buf[:, 64:128], buf[:, 128:], 1, 1, S, v_rows=True, q_log2=True)
+    assert torch.isfinite(o.float()).all()
+    ref = torch.softmax((qs.float() @ k.float().t()) / ops.LOG2E, -1) @ v.float()   # exp2(qs.k) = exp(qs.k * ln 2)
+    close(o, ref, f"attn log2 zero-base S={S} gain={gain}", rtol=2e-2, arel=3e-2)
+
+
 def test_attn_spatial_spike_forces_rescale():
     """One key row strongly aligned with one query row so the running max jumps mid-sequence (online-softmax rescale path)."""
     ops = _ops()

@@ -6,7 +6,9 @@ out={}
 for C,S,heads in ((320,9216,5),(640,2304,10),(1280,576,20)):
     g=torch.Generator(device="cuda").manual_seed(0)
     qkv=torch.randn(n*S,3*C,device="cuda",generator=g).to(torch.bfloat16)
-    fn=lambda: ops.attn_spatial(qkv[:,:C],qkv[:,C:2*C],qkv[:,2*C:],n,heads,S,v_rows=True)
+    pre=os.environ.get('ATTN_LOG2','0')=='1'
+    if pre: qkv[:,:C]*=0.18033688
+    fn=lambda: ops.attn_spatial(qkv[:,:C],qkv[:,C:2*C],qkv[:,2*C:],n,heads,S,v_rows=True,q_log2=pre)
     fn();fn();torch.cuda.synchronize()
     best=1e9
     for _ in range(4):

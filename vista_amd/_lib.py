@@ -53,6 +53,7 @@ SIGNATURES = {
     "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],
     "vk_attn_spatial_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_spatial_qkv_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "vk_attn_spatial_qkv_log2_bf16": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "vk_attn_spatial_fp8qk": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_attn_small_bf16": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_clip_preprocess_patches": [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _i32, C.POINTER(_f32), C.POINTER(_f32), _vp],

@@ -33,6 +33,7 @@
 //   LDS tile and is gathered in the accumulator's key order. HBM-bound by construction (12.5 FLOP/B).
 #include <stdlib.h>
 
+#include <type_traits>
 #include "common.h"
 #include "vista_hip.h"
 
@@ -104,7 +105,13 @@ __device__ __forceinline__ float dot2_ones(uint32_t packed, float acc) {  // acc
 // group a 4x16 -> 16x4 transpose of the 64 addressed bf16 (tools/probes/tr16_probe.hip), two reads per fragment. The lanes of a group
 // address 4 consecutive keys x 16 d; the 16-byte chunks of a row are swizzled by key bit 1 (swap of the 64-byte halves) so that the 4 rows
 // x 64 bytes a half-wave touches cover all 64 banks (tools/probes/tr16_layout_probe.hip: same rate as the b128 reads of the V^T image).
-template <int NW, int QW, bool VROW>
+// PRE: q arrives multiplied by (softmax scale x log2 e) -- folded into the query projection's weights at pack time, where it costs no extra
+// rounding -- so a score IS the base-2 exponent, and rows whose running maximum lies within +-60 octaves use the base ZERO: the probability
+// is v_exp_f32 of the accumulator itself, no scale/base fma (64 of the ~224 VALU instructions per 64-key tile and wave of a kernel that
+// is bound by its VALU, not by the matrix core: 64 quarter-rate exponentials = 1024 cycles already equal the tile's 32 MFMAs). Any base is
+// exact in exact arithmetic; base 0 is safe in fp32 / bf16 because the first tile's maximum >= -60 bounds the row sum away from zero and an
+// exponent above 127 overflows to +inf, fails the row-sum test and re-bases the row on its true maximum (general path from then on).
+template <int NW, int QW, bool VROW, bool PRE>
 __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
                                                                                 const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
                                                                                 int n_img, int heads, int S, int ldq, int ldk, int ldo,
@@ -235,7 +242,8 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
     }
 
     const int nt = n_tiles;
-    const float psum_limit = fast_exp2(fminf(rescale_thr, 100.f) + 5.f);  // finite whatever the tuning value: an overflowed row sum (+inf) must fail the test
+    const float psum_limit = PRE ? 0x1p100f : fast_exp2(fminf(rescale_thr, 100.f) + 5.f);  // finite whatever the tuning value: an overflowed row sum (+inf) must fail the test
+    bool zero_base = false;  // PRE: every row of this wave uses base 0 (wave-uniform)
     dma_tile(0, 0);
     __syncthreads();
 
@@ -280,13 +288,14 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
         // ---- probabilities under the CURRENT base m_run: the lane's 32 scores all belong to query column l31. P^T fragments: k-step
         //      J = accumulator regs 8*(J&1)..+7 of key subtile J>>1 = keys 16J + 8*lh + 0..7. The row sum is taken from the ROUNDED
         //      probabilities, two per v_dot2c_f32_bf16 (half the adds, and l matches what the PV MFMAs accumulate) ----
-        auto probabilities = [&]() {
+        auto probabilities = [&](auto zb_tag) __attribute__((always_inline)) {
+            constexpr bool ZB = decltype(zb_tag)::value;
 #pragma unroll
             for (int b = 0; b < QW; ++b) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[b][c][r] = fast_exp2(fmaf(sacc[b][c][r], scale_log2, -m_run[b]));
+                    for (int r = 0; r < 16; ++r) sacc[b][c][r] = fast_exp2(ZB ? sacc[b][c][r] : (PRE ? sacc[b][c][r] - m_run[b] : fmaf(sacc[b][c][r], scale_log2, -m_run[b])));
                 psum[b] = 0.f;
 #pragma unroll
                 for (int J = 0; J < 4; ++J) {
@@ -313,8 +322,9 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[b][0][r]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][1][r]);
-                mx = fmaxf(pair_max(mx) * scale_log2, NEG_BIG);
-                const float m_new = fmaxf(m_run[b], mx);
+                mx = fmaxf(PRE ? pair_max(mx) : pair_max(mx) * scale_log2, NEG_BIG);
+                float m_new = fmaxf(m_run[b], mx);
+                if (PRE && fabsf(m_new) <= 60.f) m_new = 0.f;
                 const float alpha = fast_exp2(m_run[b] - m_new);
                 m_run[b] = m_new;
                 l_run[b] *= alpha;
@@ -322,6 +332,20 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[b][d][r] *= alpha;
+            }
+            if constexpr (PRE) {
+                bool z = m_run[0] == 0.f;
+#pragma unroll
+                for (int b = 1; b < QW; ++b) z = z && (m_run[b] == 0.f);
+                zero_base = __all(z);
+            }
+        };
+        auto probs = [&]() __attribute__((always_inline)) {
+            if constexpr (PRE) {
+                if (zero_base) probabilities(std::true_type{});
+                else probabilities(std::false_type{});
+            } else {
+                probabilities(std::false_type{});
             }
         };
 
@@ -336,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
         // final division by l removes it. Tile 0 always takes the slow path (it defines the first base).
         scores();
         if (__builtin_expect(t == 0, 0)) rebase();
-        probabilities();
+        probs();
         bool bad = !(psum[0] <= psum_limit);
 #pragma unroll
         for (int b = 1; b < QW; ++b) bad = bad || !(psum[b] <= psum_limit);
@@ -344,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
             asm volatile("" ::: "memory");  // re-read the fragments: keeping the fast path's copies alive for this branch costs spills
             scores();
             rebase();
-            probabilities();
+            probabilities(std::false_type{});  // (the general form is right for any base, zero included)
         }
 #pragma unroll
         for (int b = 0; b < QW; ++b) l_run[b] += psum[b];
@@ -962,7 +986,7 @@ extern "C" int vk_attn_small_bf16(const void* qkv, void* o, int32_t n_img, int32
 }
 
 static int attn_spatial_launch(const void* q, const void* k, const void* vt, void* o, int32_t n_img, int32_t heads,
-                               int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream_) {
+                               int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream_, bool pre = false) {
     if (!q || !k || !vt || !o || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;
     if ((S % 8) != 0 || (ldq % 8) != 0 || (ldk % 8) != 0 || (ldo % 4) != 0) return VK_EINVAL;
     // long sequences: 256 query rows (8 waves) per workgroup halve the K/V^T stream per FLOP; short ones keep 128 rows so the
@@ -984,17 +1008,24 @@ static int attn_spatial_launch(const void* q, const void* k, const void* vt, voi
     const int nqb = (S + qb_rows - 1) / qb_rows;
     const long long nblk = (long long)nqb * n_img * heads;
     if (nblk > 0x7fffffffLL) return VK_EINVAL;
-#define ATTN_LAUNCH(NW, QW, VR)                                                                                                             \
-    hipLaunchKernelGGL((attn_spatial_kernel<NW, QW, VR>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint16_t*)q,   \
+#define ATTN_LAUNCH(NW, QW, VR, PR)                                                                                                             \
+    hipLaunchKernelGGL((attn_spatial_kernel<NW, QW, VR, PR>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint16_t*)q,   \
                        (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr, ldv)
-    if (ldv > 0) {
-        if (cls == 2) ATTN_LAUNCH(8, 2, true);
-        else if (cls == 1) ATTN_LAUNCH(8, 1, true);
-        else ATTN_LAUNCH(4, 1, true);
+    if (pre && ldv <= 0) return VK_EINVAL;  // the pre-scaled form exists for the q | k | v column-block layout only
+    if (pre) scale = 1.f / LOG2E;           // a score is already the base-2 exponent: scale_log2 = 1 for the general kernels below
+    if (pre && cls == 2) {
+        // zero-base kernel for the 512-row form only (241 VGPRs of its 256): 5.12 -> 4.95 ms per level-0 launch (1.06 -> 1.10 PFLOP/s). The
+        // 256- / 128-row forms live at 128 VGPRs for four waves per SIMD; the second probability path spills there (0.69 -> 0.81 ms at
+        // S = 2304), so they run the general kernel on the pre-scaled query (profiles/r03_attn_zero_base.txt).
+        ATTN_LAUNCH(8, 2, true, true);
+    } else if (ldv > 0) {
+        if (cls == 2) ATTN_LAUNCH(8, 2, true, false);
+        else if (cls == 1) ATTN_LAUNCH(8, 1, true, false);
+        else ATTN_LAUNCH(4, 1, true, false);
     } else {
-        if (cls == 2) ATTN_LAUNCH(8, 2, false);
-        else if (cls == 1) ATTN_LAUNCH(8, 1, false);
-        else ATTN_LAUNCH(4, 1, false);
+        if (cls == 2) ATTN_LAUNCH(8, 2, false, false);
+        else if (cls == 1) ATTN_LAUNCH(8, 1, false, false);
+        else ATTN_LAUNCH(4, 1, false, false);
     }
 #undef ATTN_LAUNCH
     VK_CHECK_LAUNCH();
@@ -1010,6 +1041,12 @@ extern "C" int vk_attn_spatial_qkv_bf16(const void* q, const void* k, const void
                                         int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float scale, void* stream_) {
     if (ldv <= 0 || (ldv % 8) != 0) return VK_EINVAL;
     return attn_spatial_launch(q, k, v, o, n_img, heads, S, ldq, ldk, ldv, ldo, scale, stream_);
+}
+
+extern "C" int vk_attn_spatial_qkv_log2_bf16(const void* q, const void* k, const void* v, void* o, int32_t n_img, int32_t heads,
+                                             int32_t S, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, void* stream_) {
+    if (ldv <= 0 || (ldv % 8) != 0) return VK_EINVAL;
+    return attn_spatial_launch(q, k, v, o, n_img, heads, S, ldq, ldk, ldv, ldo, 1.0f, stream_, true);
 }
 
 extern "C" int vk_attn_temporal_bf16(const void* qkv, void* o, int32_t B, int32_t T, int32_t S, int32_t heads, int32_t ld,

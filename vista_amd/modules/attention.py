@@ -120,6 +120,7 @@ FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1", "conv": os.enviro
 
 
 QKV_SPLIT = os.environ.get("VISTA_QKV_SPLIT", "0") == "1"  # A/B hook: spatial self-attention's projections as in round 2 (q|k + V^T GEMMs)
+Q_LOG2 = os.environ.get("VISTA_ATTN_QLOG2", "1") != "0"   # A/B hook: 0 = unscaled query rows + the scale applied inside the attention kernel
 
 
 class FeedForward(nn.Module, Packable):
@@ -272,7 +273,10 @@ class BasicTransformerBlock(nn.Module, Packable):
         # norms, so it packs those weights; attn1 / ff keep their own out-projections. norm2 only feeds the 1-token cross-attention's
         # query, which cannot influence the output (softmax over one key == 1).
         a = self.attn1
-        pk = {"qkv": ops.pack_linear_cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dev, ln=self.norm1),
+        # the query rows carry dim_head^-0.5 * log2(e) (attention.py:400-407: softmax(q k^T * scale)): one bf16 rounding of the scaled projection
+        # instead of one of the unscaled one, and the attention kernel's zero-base path needs no per-score scale / base arithmetic
+        wq = a.to_q.weight.detach().float() * (a.dim_head ** -0.5 * ops.LOG2E) if Q_LOG2 else a.to_q.weight
+        pk = {"qkv": ops.pack_linear_cat([wq, a.to_k.weight, a.to_v.weight], dev, ln=self.norm1),
               "ff_in": self.ff.pack_in_folded(self.norm3, dev)}
         if QKV_SPLIT:  # same-box A/B hook only: the round-2 form (q|k GEMM + V^T GEMM, a second pass over x)
             pk["qk"] = ops.pack_linear_cat([a.to_q.weight, a.to_k.weight], dev, ln=self.norm1)
@@ -298,13 +302,14 @@ class BasicTransformerBlock(nn.Module, Packable):
             # output leaves as MX fp8 too and the out-projection below is an fp8 GEMM -- no quantisation pass anywhere.
             v, qk8, qks = ops.linear(x, pk["qkv"], ln=stats, mx8_cols=2 * C)
             nb = C // 32
-            r8 = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], qks[:, :nb], qks[:, nb:], v, n_img, self.n_heads, S, scale, mx_out=FP8["proj"])
+            r8 = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], qks[:, :nb], qks[:, nb:], v, n_img, self.n_heads, S, 1.0 / ops.LOG2E if Q_LOG2 else scale,
+                                        mx_out=FP8["proj"])  # (pk["qkv"]'s query rows already carry scale * log2 e)
             att8, att = (r8, None) if FP8["proj"] else (None, r8)
         else:
             # ONE q|k|v GEMM (attention.py:344-346), LayerNorm(norm1) folded: x is read once and never as a normalised copy; the attention
             # kernel takes V as the third column block and transposes its tiles on the way out of LDS (no V^T tensor, no TRANS GEMM)
             qkv = ops.linear(x, pk["qkv"], ln=stats)
-            att = ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_img, self.n_heads, S, scale, v_rows=True)
+            att = ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_img, self.n_heads, S, scale, v_rows=True, q_log2=Q_LOG2)
         cv = self.attn2.context_vector(context)  # attn2(norm2(x), context): constant over the image's tokens
         if att8 is not None:
             if "out8" not in a1:  # the switch was flipped after the bf16 pack was built

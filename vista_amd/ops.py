@@ -612,9 +612,14 @@ def linear_fp8(xq, a_scale, pw, *, out=None, out_f32=False, rowvec=None, rows_pe
 PROFILE_ATTN = None  # bench.py sets this to a list: (S, n_img*heads, start_event, end_event) per launch, on the launch stream
 
 
-def attn_spatial(q, k, vt, n_img, heads, S, scale=None, v_rows=False):
+LOG2E = 1.4426950408889634
+
+
+def attn_spatial(q, k, vt, n_img, heads, S, scale=None, v_rows=False, q_log2=False):
     """q, k: 2-D strided views (n_img*S, heads*64) bf16. vt: (n_img, heads*64, S) = V transposed (linear_vt), or with v_rows=True a
-    2-D strided view (n_img*S, heads*64) like q and k -- the v column block of ONE fused q|k|v GEMM. Returns (n_img*S, heads*64)."""
+    2-D strided view (n_img*S, heads*64) like q and k -- the v column block of ONE fused q|k|v GEMM. Returns (n_img*S, heads*64).
+    q_log2 (with v_rows): q already carries softmax_scale * log2(e) (folded into the query weights at pack time), so q.k is the base-2
+    exponent itself and the kernel's zero-base path needs no scale / base fma (vk_attn_spatial_qkv_log2_bf16); `scale` is not used."""
     _need(q, BF16, "q"); _need(k, BF16, "k"); _need(vt, BF16, "v" if v_rows else "vt")
     o = torch.empty((n_img * S, heads * 64), dtype=BF16, device=q.device)
     lib = _lib.load()
@@ -626,8 +631,12 @@ def attn_spatial(q, k, vt, n_img, heads, S, scale=None, v_rows=False):
     if v_rows:
         if vt.dim() != 2 or vt.stride(1) != 1 or vt.shape != (n_img * S, heads * 64):
             raise ValueError("attn_spatial: v must be a (n_img*S, heads*64) view with contiguous rows")
-        check(lib.vk_attn_spatial_qkv_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), vt.stride(0), o.stride(0), sc,
-                                           _stream()), "vk_attn_spatial_qkv_bf16")
+        if q_log2:
+            check(lib.vk_attn_spatial_qkv_log2_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), vt.stride(0), o.stride(0),
+                                                    _stream()), "vk_attn_spatial_qkv_log2_bf16")
+        else:
+            check(lib.vk_attn_spatial_qkv_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), vt.stride(0), o.stride(0), sc,
+                                               _stream()), "vk_attn_spatial_qkv_bf16")
     else:
         check(lib.vk_attn_spatial_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), o.stride(0), sc, _stream()),
               "vk_attn_spatial_bf16")
