@@ -179,6 +179,8 @@ class FusedLoop:
             ts = torch.full((n_ts,), c_noise, device=self.xw.device)
             return self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.unet_shard)
         g = self._graph
+        if g is not None and (g["in"].shape != net_in.shape or g["ts"].shape[0] != n_ts):
+            g = self._graph = None  # another window geometry: capture again
         if g is None:
             g = self._graph = {"in": torch.empty_like(net_in), "ts": torch.empty((n_ts,), device=self.xw.device)}
             g["in"].copy_(net_in)
