@@ -175,7 +175,8 @@ int vk_clip_preprocess_patches(const float* img, void* out, int32_t n_img, int32
  * fused q|k|v projection's epilogue (VkGemmDesc.mx8_out). S^T = K . Q^T runs as v_mfma_scale_f32_32x32x64_f8f6f4 with both block scales applied
  * inside the instruction; softmax, bf16 P and P.V on the bf16 V rows (v / ldv as in vk_attn_spatial_qkv_bf16) are unchanged.
  * Output: bf16 `o` (ldo), or -- o8 != NULL -- MX fp8: e4m3 bytes at o8 + row*ldo8 + head*64 and E8M0 scales at o_scales + row*ldos + 2*head + block,
- * which an fp8 attention-out projection consumes through VkFp8Args.a_mx (attention.py:391-421). */
+ * which an fp8 attention-out projection consumes through VkFp8Args.a_mx (attention.py:391-421).
+ * scale == 0: q already carries softmax_scale * log2(e) (the pre-scaled query of vk_attn_spatial_qkv_log2_bf16; zero-base softmax). */
 int vk_attn_spatial_fp8qk(const void* q8, const void* k8, const void* q_scales, const void* k_scales, const void* v, void* o, void* o8,
                           void* o_scales, int32_t n_img, int32_t heads, int32_t S, int32_t ldq8, int32_t ldk8, int32_t ldqs, int32_t ldks,
                           int32_t ldv, int32_t ldo, int32_t ldo8, int32_t ldos, float scale, void* stream);

@@ -263,6 +263,18 @@ def test_attn_spatial_fp8qk_exact_against_dequantised_operands(n_img, heads, S):
     rms = ref.pow(2).mean().sqrt()
     assert (e <= 2e-2 * rms + 1.6e-2 * ref.abs()).all(), f"max err {e.max().item()} rms {rms.item()}"
     assert rel_l2(got, ref) < 6e-3
+    # scale = 0: "q already carries scale * log2 e" (what BasicTransformerBlock packs): fold a power of two into q's block scales instead and
+    # compare with softmax(q k^T * 2^sh * ln 2); S >= 4096 runs the zero-base 512-row kernel, shorter ones the general kernel with scale_log2 = 1
+    import math
+    sh = round(math.log2(scale * 1.4426950408889634))
+    sc2 = sc.clone()
+    sc2[:, :nb] = (sc2[:, :nb].to(torch.int16) + sh).clamp(1, 254).to(torch.uint8)
+    got0 = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], sc2[:, :nb], sc2[:, nb:], v, n_img, heads, S, scale=0.0)
+    ref0 = torch.nn.functional.scaled_dot_product_attention(q, k, vv, scale=2.0 ** sh * math.log(2.0)).transpose(1, 2).reshape(M, C)
+    e0 = (got0.float() - ref0).abs()
+    rms0 = ref0.pow(2).mean().sqrt()
+    assert torch.isfinite(got0).all() and (e0 <= 2e-2 * rms0 + 1.6e-2 * ref0.abs()).all(), f"pre-scaled: max err {e0.max().item()} rms {rms0.item()}"
+    assert rel_l2(got0, ref0) < 6e-3
     # MX fp8 output of the same kernel: the e4m3 rounding of the bf16 output under the tightest block scale, pad scale bytes = 2^0
     o8, osc = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], sc[:, :nb], sc[:, nb:], v, n_img, heads, S, scale=scale, mx_out=True)
     assert o8.shape == (M, C) and osc.shape[0] == M and osc.shape[1] % 4 == 0 and osc.shape[1] >= nb

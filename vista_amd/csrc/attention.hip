@@ -608,7 +608,8 @@ extern "C" int vk_softmax_rows_f32_bf16(const float* x, void* y, int64_t rows, i
 namespace {
 typedef __attribute__((ext_vector_type(8))) int i32x8a_t;
 
-template <int NW, int QW>
+// PRE: as in attn_spatial_kernel -- the query carries scale x log2 e, zero-base rows take v_exp_f32 of the score itself (512-row form only).
+template <int NW, int QW, bool PRE>
 __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_kernel(const uint8_t* __restrict__ q8, const uint8_t* __restrict__ k8,
                                                                                       const uint8_t* __restrict__ qs, const uint8_t* __restrict__ ks,
                                                                                       const uint16_t* __restrict__ v, uint16_t* __restrict__ o,
@@ -715,7 +716,8 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[b][d][r] = 0.f;
     }
-    const float psum_limit = fast_exp2(fminf(rescale_thr, 100.f) + 5.f);
+    const float psum_limit = PRE ? 0x1p100f : fast_exp2(fminf(rescale_thr, 100.f) + 5.f);
+    bool zero_base = false;
     int ksc[2], ksc_next[2];
     dma_tile(0, 0);
     k_scales(0, ksc);
@@ -757,13 +759,14 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
                     }
             }
         };
-        auto probabilities = [&]() __attribute__((always_inline)) {
+        auto probabilities = [&](auto zb_tag) __attribute__((always_inline)) {
+            constexpr bool ZB = decltype(zb_tag)::value;
 #pragma unroll
             for (int b = 0; b < QW; ++b) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sacc[b][c][r] = fast_exp2(fmaf(sacc[b][c][r], scale_log2, -m_run[b]));
+                    for (int r = 0; r < 16; ++r) sacc[b][c][r] = fast_exp2(ZB ? sacc[b][c][r] : (PRE ? sacc[b][c][r] - m_run[b] : fmaf(sacc[b][c][r], scale_log2, -m_run[b])));
                 psum[b] = 0.f;
 #pragma unroll
                 for (int J = 0; J < 4; ++J) {
@@ -789,8 +792,9 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[b][0][r]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][1][r]);
-                mx = fmaxf(pair_max(mx) * scale_log2, NEG_BIG);
-                const float m_new = fmaxf(m_run[b], mx);
+                mx = fmaxf(PRE ? pair_max(mx) : pair_max(mx) * scale_log2, NEG_BIG);
+                float m_new = fmaxf(m_run[b], mx);
+                if (PRE && fabsf(m_new) <= 60.f) m_new = 0.f;
                 const float alpha = fast_exp2(m_run[b] - m_new);
                 m_run[b] = m_new;
                 l_run[b] *= alpha;
@@ -799,11 +803,22 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
 #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[b][d][r] *= alpha;
             }
+            if constexpr (PRE) {
+                bool z = m_run[0] == 0.f;
+#pragma unroll
+                for (int b = 1; b < QW; ++b) z = z && (m_run[b] == 0.f);
+                zero_base = __all(z);
+            }
         };
         // the bf16 kernel's max-free fast path (see attn_spatial_kernel): exponentials against the existing base, validated by the row sums
         scores();
         if (__builtin_expect(t == 0, 0)) rebase();
-        probabilities();
+        if constexpr (PRE) {
+            if (zero_base) probabilities(std::true_type{});
+            else probabilities(std::false_type{});
+        } else {
+            probabilities(std::false_type{});
+        }
         bool bad = !(psum[0] <= psum_limit);
 #pragma unroll
         for (int b = 1; b < QW; ++b) bad = bad || !(psum[b] <= psum_limit);
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
             asm volatile("" ::: "memory");
             scores();
             rebase();
-            probabilities();
+            probabilities(std::false_type{});
         }
 #pragma unroll
         for (int b = 0; b < QW; ++b) l_run[b] += psum[b];
@@ -885,13 +900,16 @@ extern "C" int vk_attn_spatial_fp8qk(const void* q8, const void* k8, const void*
     const int qb_rows = cls == 2 ? 512 : (cls == 1 ? 256 : 128);
     const long long nblk = (long long)((S + qb_rows - 1) / qb_rows) * n_img * heads;
     if (nblk > 0x7fffffffLL) return VK_EINVAL;
-#define FP8QK_LAUNCH(NW, QW)                                                                                                                    \
-    hipLaunchKernelGGL((attn_spatial_fp8qk_kernel<NW, QW>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint8_t*)q8,       \
+    const bool pre = scale == 0.f;  // scale == 0: the query already carries softmax_scale * log2(e) (see vk_attn_spatial_qkv_log2_bf16)
+    if (pre) scale = 1.f / LOG2E;
+#define FP8QK_LAUNCH(NW, QW, PR)                                                                                                                \
+    hipLaunchKernelGGL((attn_spatial_fp8qk_kernel<NW, QW, PR>), dim3((unsigned)nblk), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint8_t*)q8,   \
                        (const uint8_t*)k8, (const uint8_t*)q_scales, (const uint8_t*)k_scales, (const uint16_t*)v, (uint16_t*)o, (uint8_t*)o8,     \
                        (uint8_t*)o_scales, n_img, heads, S, ldq8, ldk8, ldqs, ldks, ldv, ldo, ldo8, ldos, scale * LOG2E, thr)
-    if (cls == 2) FP8QK_LAUNCH(8, 2);
-    else if (cls == 1) FP8QK_LAUNCH(8, 1);
-    else FP8QK_LAUNCH(4, 1);
+    if (cls == 2 && pre) FP8QK_LAUNCH(8, 2, true);
+    else if (cls == 2) FP8QK_LAUNCH(8, 2, false);
+    else if (cls == 1) FP8QK_LAUNCH(8, 1, false);
+    else FP8QK_LAUNCH(4, 1, false);
 #undef FP8QK_LAUNCH
     VK_CHECK_LAUNCH();
     return VK_OK;

@@ -302,7 +302,7 @@ class BasicTransformerBlock(nn.Module, Packable):
             # output leaves as MX fp8 too and the out-projection below is an fp8 GEMM -- no quantisation pass anywhere.
             v, qk8, qks = ops.linear(x, pk["qkv"], ln=stats, mx8_cols=2 * C)
             nb = C // 32
-            r8 = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], qks[:, :nb], qks[:, nb:], v, n_img, self.n_heads, S, 1.0 / ops.LOG2E if Q_LOG2 else scale,
+            r8 = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], qks[:, :nb], qks[:, nb:], v, n_img, self.n_heads, S, 0.0 if Q_LOG2 else scale,
                                         mx_out=FP8["proj"])  # (pk["qkv"]'s query rows already carry scale * log2 e)
             att8, att = (r8, None) if FP8["proj"] else (None, r8)
         else:

@@ -649,7 +649,8 @@ def attn_spatial(q, k, vt, n_img, heads, S, scale=None, v_rows=False, q_log2=Fal
 def attn_spatial_fp8qk(q8, k8, qs, ks, v, n_img, heads, S, scale=None, mx_out=False):
     """BASELINE config 5: spatial self-attention with the score product in fp8. q8 / k8: (n_img*S, heads*64) uint8 views of e4m3 bytes (rows
     may be strided: the q | k blocks of linear(..., mx8_cols=2C)); qs / ks: (n_img*S, 2*heads) uint8 views of their E8M0 block scales; v:
-    (n_img*S, heads*64) bf16 rows. Returns bf16 (n_img*S, heads*64), or with mx_out=True (o8 uint8 (M, C), o_scales uint8 (M, C/32))."""
+    (n_img*S, heads*64) bf16 rows. Returns bf16 (n_img*S, heads*64), or with mx_out=True (o8 uint8 (M, C), o_scales uint8 (M, C/32)).
+    scale=0.0: q already carries softmax_scale * log2(e) (the pre-scaled query of attn_spatial(..., q_log2=True))."""
     _need(v, BF16, "v")
     for name, t in (("q8", q8), ("k8", k8), ("qs", qs), ("ks", ks)):
         if t.dtype != torch.uint8 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
