@@ -19,7 +19,10 @@ x = torch.randn(M, C, device="cuda").to(BF16)
 if kind == "attn":  # the product form since round 3: q | k | v column blocks of ONE GEMM, V read row-major (ds_read_b64_tr_b16)
     pqkv = ops.pack_linear_cat([torch.randn(C, C) * C ** -0.5 for _ in range(3)])
     qkv = ops.linear(x, pqkv)
-    fn = lambda: ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], N, heads, S, v_rows=True)  # noqa: E731
+    pre = os.environ.get("ATTN_LOG2", "1") == "1"  # the product form: pre-scaled query, zero-base softmax in the 512-row kernel
+    if pre:
+        qkv[:, :C] *= 0.18033688
+    fn = lambda: ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], N, heads, S, v_rows=True, q_log2=pre)  # noqa: E731
 elif kind == "conv":
     pc = ops.pack_conv3x3(torch.randn(C, C, 3, 3) * (9 * C) ** -0.5, torch.randn(C))
     x3 = x.view(N, S, C)
