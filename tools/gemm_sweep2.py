@@ -60,7 +60,10 @@ def main():
                 x, pw, res1=res, rowvec=rv, rows_per_vec=H * W, emit_stats=True), 2.0 * M * C * C),
             "conv_t3": (lambda pw=ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C)): ops.conv_t3(x3, pw, T, H * W), 2.0 * M * 3 * C * C),
         }
+        only = os.environ.get("SWEEP_KINDS")
         for name, (fn, flop) in cases.items():
+            if only and not any(k in name for k in only.split(",")):
+                continue
             best = {}
             for _ in range(3):
                 for f in flags:

@@ -462,9 +462,11 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
         //  * GEGLU walks its tile list with 256 persistent workgroups, so its time is ceil(tiles / 256) tile-times: 4032 x 10240 x 1280 is
         //    640 tiles of 256x256 = 3 rounds but 512 tiles of 256x320 = exactly 2 (126 -> 108 us); the wider tile is ~5 % slower per
         //    FLOP (the 2-9 % measured at full size, where the rounds are 18 / 36 / 71 and the rule keeps 256x256).
+        //    Since the LDS-staged epilogue the wider tile is no longer slower per FLOP once K >= 640 (same-box sweep, 50 images: level 1
+        //    0.875 -> 0.842 ms, level 2 0.740 -> 0.738; level 0 / K = 320 1.037 -> 1.079, where it stays 5 % behind): weight it +3 % there.
         if (epi == EPI_GEGLU && amode == AMODE_DENSE && (d->N % 320) == 0 && cfg == 3) {
             const long long r3 = (wgs(256, 256) + 255) / 256, r4 = (wgs(256, 320) + 255) / 256;
-            if (r4 * 320 * 100 < r3 * 256 * 95) cfg = 4;
+            if (r4 * 320 * 100 < r3 * 256 * (d->K >= 640 ? 103 : 95)) cfg = 4;
         }
         //  * DENSE LINEAR: when the tile picked above fills < 75 % of its last round (e.g. 16128 x 640: 126 tiles of 256x320 do not reach
         //    `need`, 315 of 256x128 are 1.23 rounds), 128x160 tiles -- two co-resident workgroups per CU, which degrade gracefully in a
