@@ -1,31 +1,35 @@
-"""Sigma schedules (reference: vwm/modules/diffusionmodules/discretizer.py:16-37). Evaluated once per sampling call with
-the reference's exact fp32 torch expressions, so the schedule is bit-identical to the reference's."""
-from abc import abstractmethod
+"""Noise-level schedules of the sampler (what the reference keeps in vwm/modules/diffusionmodules/discretizer.py:16-37).
 
+The schedule is evaluated ONCE per sampling call, on the host in fp32 with the same torch expression order as the reference
+(scalar roots in Python floats, one `linspace`, one fused affine map, one tensor power), so every sigma is bit-identical to the
+reference's and identical on every rank of a multi-GPU run; only the finished vector moves to the device."""
 import torch
 
 from ...util import append_zero
 
 
 class Discretization:
-    def __call__(self, n, do_append_zero=True, device="cpu", flip=False):
-        sigmas = self.get_sigmas(n, device=device)
-        sigmas = append_zero(sigmas) if do_append_zero else sigmas
-        return sigmas if not flip else torch.flip(sigmas, (0,))
+    """Callable schedule: `disc(n, do_append_zero=True, device=..., flip=False)` -> (n [+1],) fp32 sigmas, largest first."""
 
-    @abstractmethod
     def get_sigmas(self, n, device):
-        pass
+        raise NotImplementedError("a Discretization provides get_sigmas(n, device)")
+
+    def __call__(self, n, do_append_zero=True, device="cpu", flip=False):
+        schedule = self.get_sigmas(n, device=device)
+        if do_append_zero:
+            schedule = append_zero(schedule)  # the trailing sigma = 0 the Euler loop steps onto
+        if flip:
+            schedule = schedule.flip(0)
+        return schedule
 
 
 class EDMDiscretization(Discretization):
+    """Karras et al. (EDM) rho-schedule: sigma_i = (smax^(1/rho) + i/(n-1) * (smin^(1/rho) - smax^(1/rho)))^rho."""
+
     def __init__(self, sigma_min=0.002, sigma_max=80.0, rho=7.0):
         self.sigma_min, self.sigma_max, self.rho = sigma_min, sigma_max, rho
 
     def get_sigmas(self, n, device="cpu"):
-        # computed on the host (fp32) and moved: identical values on every device, no device-side pow/linspace drift
-        ramp = torch.linspace(0, 1, n)
-        min_inv_rho = self.sigma_min ** (1 / self.rho)
-        max_inv_rho = self.sigma_max ** (1 / self.rho)
-        sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** self.rho
-        return sigmas.to(device)
+        root_lo, root_hi = (s ** (1 / self.rho) for s in (self.sigma_min, self.sigma_max))
+        t = torch.linspace(0, 1, n)  # host fp32: no device-side linspace / pow drift between back-ends
+        return ((root_hi + t * (root_lo - root_hi)) ** self.rho).to(device)
