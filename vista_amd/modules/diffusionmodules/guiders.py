@@ -23,14 +23,17 @@ class Guider(ABC):
 
 
 def _cfg_prepare(x, s, c, cond_mask, uc, keys):
-    c_out = dict()
-    for k in c:
-        if k in keys:
-            c_out[k] = torch.cat((uc[k], c[k]), 0)
+    """The CFG-doubled batch: [unconditional | conditional] along dim 0 for x, sigma, the mask and every conditioning entry in `keys`;
+    entries outside `keys` must be the same object in both dicts and pass through (guiders.py:30-38,76-84)."""
+    doubled = {}
+    for name, value in c.items():
+        if name in keys:
+            doubled[name] = torch.cat((uc[name], value), 0)
         else:
-            assert c[k] == uc[k]
-            c_out[k] = c[k]
-    return torch.cat([x] * 2), torch.cat([s] * 2), c_out, torch.cat([cond_mask] * 2)
+            assert value == uc[name]
+            doubled[name] = value
+    twice = lambda t: torch.cat((t, t))  # noqa: E731
+    return twice(x), twice(s), doubled, twice(cond_mask)
 
 
 class VanillaCFG(Guider):
@@ -84,19 +87,17 @@ class TrianglePredictionGuider(LinearPredictionGuider):
                  period_fusing: Literal["mean", "multiply", "max"] = "max",
                  additional_cond_keys: Optional[Union[List[str], str]] = None):
         super().__init__(num_frames, max_scale, min_scale, additional_cond_keys)
-        values = torch.linspace(0, 1, num_frames)
-        if isinstance(period, float):
-            period = [period]
-        scales = [self.triangle_wave(values, p) for p in period]
+        ramp = torch.linspace(0, 1, num_frames)
+        waves = torch.stack([self.triangle_wave(ramp, p) for p in ([period] if isinstance(period, float) else period)])
         if period_fusing == "mean":
-            scale = sum(scales) / len(period)
+            fused = sum(waves) / waves.shape[0]
         elif period_fusing == "multiply":
-            scale = torch.prod(torch.stack(scales), dim=0)
+            fused = torch.prod(waves, dim=0)
         elif period_fusing == "max":
-            scale = torch.max(torch.stack(scales), dim=0).values
+            fused = torch.max(waves, dim=0).values
         else:
             raise NotImplementedError
-        self.scale = (scale * (max_scale - min_scale) + min_scale).unsqueeze(0)
+        self.scale = (fused * (max_scale - min_scale) + min_scale).unsqueeze(0)
 
     def triangle_wave(self, values, period):
         return 2 * (values / period - torch.floor(values / period + 0.5)).abs()
