@@ -21,8 +21,6 @@ names; weights come from the checkpoint (`conditioner.embedders.0.open_clip.mode
 `transformers.CLIPVisionModelWithProjection` -- the same published algorithm -- in oracle/clip_oracle.py.
 Training-time options (ucg dropout, image crops, token outputs, sigma samplers) raise NotImplementedError with the option named.
 """
-import math
-from contextlib import nullcontext
 
 import torch
 import torch.nn as nn

@@ -5,8 +5,6 @@ sample_utils.py:148-229 resolve to the MI355X classes without being edited."""
 import functools
 import importlib
 
-import torch
-
 _TARGET_PREFIXES = (("vwm.modules.", "vista_amd.modules."), ("vwm.models.", "vista_amd.models."), ("vwm.util", "vista_amd.util"))
 _PLACEHOLDER_CONFIGS = ("__is_first_stage__", "__is_unconditional__")  # config strings that stand for "no object"
 
