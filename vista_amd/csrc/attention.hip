@@ -1013,7 +1013,7 @@ static int attn_spatial_launch(const void* q, const void* k, const void* vt, voi
     // long sequences: 8 waves x 64 query rows (512 per workgroup): every K / V^T fragment read feeds two MFMAs and the K/V^T stream
     // per FLOP halves again; medium ones 8 x 32; short ones 4 x 32 so the ragged last q-block wastes less (S = 144, 576 at the deep levels)
     static const int qw_env = [] { const char* e = getenv("VISTA_ATTN_QW"); return e ? atoi(e) : 0; }();  // tuning / A-B: 1 or 2
-    int cls = S >= 4096 ? (qw_env == 1 ? 1 : 2) : (S >= 2048 ? 1 : 0);
+    int cls = S >= 4096 ? (qw_env == 1 ? 1 : 2) : (S >= 2048 ? (qw_env == 2 ? 2 : 1) : 0);
     if (cls == 2 && qw_env == 0) {
         // few images (one rank of a frame-sharded run): the 512-row workgroups run ONE per CU, so e.g. 7 images x 5 heads x 18 blocks = 630 of
         // them are 2.46 rounds = 3; 256-row workgroups (two per CU) finish the same work 8.5 % sooner (0.88 -> 0.805 ms), while at 8 / 13 / 50
