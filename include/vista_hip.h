@@ -79,6 +79,9 @@ int vk_gemm_bf16(const VkGemmDesc* d, void* stream);
 /* Number of partial-sum slabs vk_gemm_bf16 would write to d->rowstat_out for this problem (depends on the block tile the launcher
  * picks: column tiles x wave columns); > 0, or a negative error code. Pure host function, no launch. */
 int vk_gemm_rowstat_parts(const VkGemmDesc* d);
+/* The launcher's decision for `desc` without launching anything (host arithmetic only): block-tile variant (1 = 128x128, 2 = 256x128,
+ * 3 = 256x256, 4 = 256x320, 5 = 128x160) * 16 + number of K slices; negative = the error vk_gemm_bf16 would return. */
+int vk_gemm_tile_choice(const VkGemmDesc* d);
 
 /* fp8 (OCP e4m3) variant of the DENSE GEMM for the UNet's Linear / 1x1 projections (BASELINE.json config 5: "fp8 1x1
  * conv-as-GEMM path"; same reference call sites as vk_gemm_bf16's DENSE mode: attention.py:268-285,97-128, video_attention.py).

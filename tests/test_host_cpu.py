@@ -382,3 +382,53 @@ def test_config_fallback_equals_shipped_yaml_and_import_is_lazy():
         cfg.CONFIG_PATH = real
         cfg.load_config.__defaults__ = (real,)
         cfg._UNET_KWARGS = saved
+
+
+def test_gemm_launch_rules_are_pinned():
+    """vk_gemm_tile_choice: the launcher's (block tile, K slices) for the BASELINE shapes and for one rank of an 8-GPU run, as host arithmetic
+    (no GPU). Pins what the same-box sweeps of rounds 1-3 chose (profiles/r03_tile5_sweep.txt, r03_gemm_sweep_rank7*.jsonl,
+    r03_geglu_two_per_cu_experiment.txt): a changed rule must change this table knowingly."""
+    import ctypes as C
+    from vista_amd import _lib, ops
+    lib = _lib.load()
+    one = C.c_void_p(16)  # never dereferenced by the query: any non-null pointer passes validate()
+
+    def choice(M, N, K, epi=ops.EPI_LINEAR, amode=ops.AMODE_DENSE, stats=False, ws=True, Cin=0, **kw):
+        d = _lib.VkGemmDesc()
+        d.A = d.Wt = d.out = one
+        d.M, d.N, d.K, d.lda, d.ldc = M, N, K, K, (N // 2 if epi == ops.EPI_GEGLU else N)
+        d.amode, d.epi, d.alpha = amode, epi, 1.0
+        if stats:
+            d.rowstat_out = one
+        if ws:
+            d.splitk_ws, d.splitk_ws_bytes = one, 160 << 20
+        if amode != ops.AMODE_DENSE:
+            d.Cin, d.H, d.Wd, d.Hout, d.Wout, d.stride, d.ups = Cin, kw["H"], kw["W"], kw["H"], kw["W"], 1, 1
+        for k, v in kw.items():
+            if k not in ("H", "W"):
+                setattr(d, k, v)
+        rc = lib.vk_gemm_tile_choice(C.byref(d))
+        assert rc > 0, f"vk_gemm_tile_choice({M},{N},{K}) -> {rc}"
+        return divmod(rc, 16)
+
+    full, L1, L2 = 50 * 9216, 50 * 2304, 50 * 576
+    # one GPU, 50 images
+    assert choice(full, 320, 320, stats=True) == (5, 1)         # K = N projections: 128x160, two workgroups per CU
+    assert choice(L1, 640, 640, stats=True) == (5, 1)
+    assert choice(L2, 1280, 1280, stats=True) == (4, 1)         # K = N = 1280: back on the big tile
+    assert choice(full, 960, 320) == (4, 1)                     # q|k|v: N = 3K
+    assert choice(full, 320, 1280, stats=True) == (4, 1)        # FeedForward out: K = 4N
+    assert choice(full, 2560, 320, epi=ops.EPI_GEGLU) == (3, 1)
+    assert choice(L1, 5120, 640, epi=ops.EPI_GEGLU) == (4, 1)   # 256x320 since the LDS-staged epilogue (K >= 640)
+    assert choice(L2, 10240, 1280, epi=ops.EPI_GEGLU) == (3, 1)
+    assert choice(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128) == (4, 1)
+    # one rank of 8 (7 images)
+    r0, r1, r2 = 7 * 9216, 7 * 2304, 7 * 576
+    assert choice(r0, 320, 1280, stats=True) == (4, 1)          # 252 tiles: one full round
+    assert choice(r1, 640, 640, stats=True) == (5, 1)           # 126 tiles of 256x320 would fill half the chip
+    assert choice(r1, 640, 2560, stats=True) == (5, 1)
+    assert choice(r2, 1280, 5120, stats=True) == (5, 1)
+    assert choice(r2, 10240, 1280, epi=ops.EPI_GEGLU) == (4, 1)  # 512 tiles = 2 rounds instead of 640 = 3
+    cfg, ks = choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32)
+    assert cfg == 4 and ks >= 2, "small-M deep-K convolutions run split-K on the big tile"
+    assert choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32, ws=False) [1] == 1  # no workspace, no split

@@ -45,6 +45,7 @@ ABI_VERSION = 3  # vk_abi_version() of the library this table mirrors
 SIGNATURES = {
     "vk_gemm_bf16": [C.POINTER(VkGemmDesc), _vp],
     "vk_gemm_rowstat_parts": [C.POINTER(VkGemmDesc)],
+    "vk_gemm_tile_choice": [C.POINTER(VkGemmDesc)],
     "vk_gemm_fp8": [C.POINTER(VkGemmDesc), _vp, _vp, _i32, _vp],
     "vk_gemm_fp8_mx": [C.POINTER(VkGemmDesc), C.POINTER(VkFp8Args), _vp],
     "vk_gemm_fp8_rowstat_parts": [C.POINTER(VkGemmDesc)],

@@ -567,6 +567,15 @@ extern "C" int vk_gemm_rowstat_parts(const VkGemmDesc* d) {
     return ((d->N + bn - 1) / bn) * wn;
 }
 
+// The launcher's decision for `d`, without launching: (block-tile variant 1..5) * 16 + K slices. Pure host arithmetic (the CPU test-suite pins
+// the launch rules with it); negative = the error vk_gemm_bf16 would return.
+extern "C" int vk_gemm_tile_choice(const VkGemmDesc* d) {
+    const int rc = validate(d);
+    if (rc != VK_OK) return rc;
+    const TileChoice t = choose_tile(d);
+    return t.cfg * 16 + t.ksplit;
+}
+
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int rc = validate(d);
