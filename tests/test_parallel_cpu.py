@@ -11,6 +11,62 @@ import torch.multiprocessing as mp
 from vista_amd.parallel import DistComm, FrameShard, ThreadComm, offsets, split_counts
 
 
+def _check_chunked_way_back(shard, X, chunks):
+    """to_frames_begin / to_frames_end over pixel sub-ranges == the one-shot to_frames, bit for bit."""
+    B, T, S, C = X.shape
+    r = shard.rank
+    so = offsets(shard.pixel_counts(S))
+    y = X[:, :, so[r]:so[r + 1]].reshape(B * T, -1, C).contiguous()          # this rank's pixel-sharded tensor
+    want = shard.to_frames(y, S)
+    out = torch.full_like(want, float("nan"))
+    parts = shard.pixel_chunks(S, chunks)
+    assert parts[0][0] == 0 and parts[-1][1] == y.shape[1] and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    pending = [shard.to_frames_begin(y[:, lo:hi].contiguous(), S, chunks, c) for c, (lo, hi) in enumerate(parts)]
+    for p in pending:
+        shard.to_frames_end(p, out)
+    assert torch.equal(out, want), "chunked pixels->frames must equal the one-shot exchange"
+
+
+@pytest.mark.parametrize("P,T,S,chunks", [(2, 5, 16, 2), (3, 7, 10, 3), (4, 25, 18, 2), (8, 25, 144, 2), (4, 25, 37, 3)])
+def test_chunked_way_back_thread_ranks(P, T, S, chunks):
+    B, C = 2, 8
+    X = torch.randn(B, T, S, C)
+    shared = ThreadComm.Shared(P)
+    errs = []
+
+    def run(rank):
+        try:
+            _check_chunked_way_back(FrameShard(T, ThreadComm(shared, rank), B=B), X, chunks)
+        except Exception:  # noqa: BLE001
+            import traceback
+            errs.append(traceback.format_exc())
+            shared.barrier.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs[0]
+
+
+def _gloo_chunk_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        X = torch.randn(2, 7, 11, 8)
+        sh = FrameShard(7, DistComm(), B=2)
+        for chunks in (2, 3):
+            _check_chunked_way_back(sh, X, chunks)   # async_op=True Work handles over real processes (gloo), 11 pixels over 3 ranks: 4/4/3
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_way_back_gloo_three_processes():
+    port = 29900 + (os.getpid() % 1500)
+    mp.spawn(_gloo_chunk_worker, args=(3, port), nprocs=3, join=True)
+
+
 def test_split_counts_matches_baseline_partition():
     assert split_counts(25, 8) == [4, 3, 3, 3, 3, 3, 3, 3]  # BASELINE.json config 3
     assert split_counts(25, 4) == [7, 6, 6, 6] and split_counts(25, 2) == [13, 12] and split_counts(25, 1) == [25]

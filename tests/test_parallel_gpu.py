@@ -38,8 +38,10 @@ def run_ranks(P, fn):
     return out
 
 
-@pytest.mark.parametrize("P", [2, 3])
-def test_sharded_unet_forward_matches_unsharded_and_golden(P):
+@pytest.mark.parametrize("P,chunks", [(2, 1), (3, 1), (2, 2), (3, 3)])
+def test_sharded_unet_forward_matches_unsharded_and_golden(P, chunks, monkeypatch):
+    """chunks > 1 = VISTA_A2A_CHUNKS: the temporal block on pixel sub-ranges with one (asynchronously started) all-to-all per sub-range."""
+    monkeypatch.setenv("VISTA_A2A_CHUNKS", str(chunks))
     from oracle.make_golden import unet_inputs
     from tests.test_model_gpu import tiny_unet
     from vista_amd import ops
@@ -64,8 +66,9 @@ def test_sharded_unet_forward_matches_unsharded_and_golden(P):
     r_un = rel_l2(full, ref_tok)
     gold = g["out"].cuda().permute(0, 2, 3, 1).reshape(2 * T, H * W, 4)
     r_gold = rel_l2(full, gold)
-    print(f"[parity] sharded P={P}: vs unsharded {r_un:.3e}, vs reference golden {r_gold:.3e}")
+    print(f"[parity] sharded P={P} chunks={chunks}: vs unsharded {r_un:.3e}, vs reference golden {r_gold:.3e}")
     assert r_un <= 2.5e-2 and r_gold <= 2.5e-2
+    assert all(sh.a2a_chunks == chunks for sh, _ in outs)
 
 
 def test_sharded_sampler_matches_golden():

@@ -19,7 +19,7 @@ class MockComm:
     def __init__(self, ranks, rank):
         self.world, self.rank = len(ranks), ranks.index(rank)
 
-    def all_to_all(self, recv, send, out_splits, in_splits):
+    def all_to_all(self, recv, send, out_splits, in_splits, async_op=False):
         recv.zero_()
 
     def all_reduce_sum(self, t):
@@ -36,9 +36,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--mode", default="hybrid")
     ap.add_argument("--cprofile", action="store_true")
+    ap.add_argument("--chunks", type=int, default=1, help="VISTA_A2A_CHUNKS: temporal block on pixel sub-ranges (compute-side cost of the overlap option)")
     ap.add_argument("--graph", action="store_true", help="replay the UNet forward from one captured hipGraph (VISTA_HIPGRAPH=force: the mock collectives are plain kernels)")
     ap.add_argument("--torch-profile", action="store_true", help="per-kernel table of the timed steps only (no model-build / packing kernels)")
     a = ap.parse_args()
+    os.environ["VISTA_A2A_CHUNKS"] = str(a.chunks)
     if a.graph:
         os.environ["VISTA_HIPGRAPH"] = "force"
     import bench

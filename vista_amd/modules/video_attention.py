@@ -15,6 +15,7 @@ Every LayerNorm is folded into the GEMM that consumes it (include/vista_hip.h, V
 emits per-row (sum, sum of squares) partials of its bf16 output and the consumer applies rstd*(acc - mean*colsum) in its own
 epilogue, so no normalised tensor is written or read (7 full HBM passes per block pair less).
 """
+import torch
 import torch.nn as nn
 
 from .. import ops
@@ -168,9 +169,23 @@ class SpatialVideoTransformer(SpatialTransformer):
             else:
                 hp = shard.to_pixels(h.view(n_img, S, C))                          # (B*T, S_r, C)
                 s_r = hp.shape[1]
-                hp = hp.view(-1, C)
-                hp, _ = mix_block(hp, ops.rowstats(hp), emb, clip_context, B, T, s_r, alpha=pk["alpha"])
-                h = shard.to_frames(hp.view(B * T, s_r, C), S).view(-1, C)
+                nch = min(getattr(shard, "a2a_chunks", 1), min(shard.pixel_counts(S)))  # (the same on every rank: the narrowest slice decides)
+                if nch <= 1:
+                    hp = hp.view(-1, C)
+                    hp, _ = mix_block(hp, ops.rowstats(hp), emb, clip_context, B, T, s_r, alpha=pk["alpha"])
+                    h = shard.to_frames(hp.view(B * T, s_r, C), S).view(-1, C)
+                else:
+                    # opt-in overlap (VISTA_A2A_CHUNKS): the temporal block is pointwise in space, so it runs on pixel sub-ranges in turn and
+                    # sub-range i travels back to the frame layout while sub-range i + 1 computes
+                    out = torch.empty((n_img, S, C), dtype=hp.dtype, device=hp.device)
+                    pending = []
+                    for ci, (lo, hi) in enumerate(shard.pixel_chunks(S, nch)):
+                        part = hp[:, lo:hi].contiguous().view(-1, C)
+                        part, _ = mix_block(part, ops.rowstats(part), emb, clip_context, B, T, hi - lo, alpha=pk["alpha"])
+                        pending.append(shard.to_frames_begin(part.view(B * T, hi - lo, C), S, nch, ci))
+                    for pnd in pending:
+                        shard.to_frames_end(pnd, out)
+                    h = out.view(-1, C)
                 st = ops.rowstats(h) if i != last else None
         out = ops.linear(h, pk["proj_out"], res1=x_in)
         return out.view(n_img, S, C)

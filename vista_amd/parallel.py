@@ -39,7 +39,7 @@ class SelfComm:
     """Single-rank communicator (a frame-shard group of one rank, e.g. the CFG-only split at 2 GPUs)."""
     rank, world = 0, 1
 
-    def all_to_all(self, recv, send, out_splits, in_splits):
+    def all_to_all(self, recv, send, out_splits, in_splits, async_op=False):
         recv.copy_(send)
 
     def all_reduce_sum(self, t):
@@ -93,7 +93,9 @@ class DistComm:
         raise CollectiveError(f"[global rank {self.dist.get_rank()}] {what} on group '{self.name}' (backend {self.backend}, "
                               f"group rank {self.rank}/{self.world}) failed: {detail}: {type(e).__name__}: {e}") from e
 
-    def all_to_all(self, recv, send, out_splits, in_splits):
+    def all_to_all(self, recv, send, out_splits, in_splits, async_op=False):
+        """async_op (device-to-device backends only): returns the torch.distributed Work handle -- the exchange runs on the backend's own
+        stream behind everything enqueued so far, the caller's stream continues and `handle.wait()` orders it after the exchange."""
         if len(out_splits) != self.world or len(in_splits) != self.world or sum(out_splits) != recv.numel() or sum(in_splits) != send.numel():
             raise CollectiveError(f"all_to_all_single on group '{self.name}': split lists do not match the buffers: out_splits {out_splits} "
                                   f"(recv {recv.numel()}), in_splits {in_splits} (send {send.numel()}), group size {self.world}")
@@ -103,7 +105,7 @@ class DistComm:
                 self.dist.all_to_all_single(r, send.cpu(), out_splits, in_splits, group=self.group)
                 recv.copy_(r)
                 return
-            self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group)
+            return self.dist.all_to_all_single(recv, send, out_splits, in_splits, group=self.group, async_op=bool(async_op))
         except CollectiveError:
             raise
         except Exception as e:  # noqa: BLE001
@@ -179,7 +181,7 @@ class ThreadComm:
         sh.barrier.wait()
         return got
 
-    def all_to_all(self, recv, send, out_splits, in_splits):
+    def all_to_all(self, recv, send, out_splits, in_splits, async_op=False):
         got = self._exchange((send, in_splits))
         pos = 0
         for q in range(self.world):
@@ -229,6 +231,11 @@ class FrameShard:
         self.t_off = offsets(self.t_counts)
         self.t_local = self.t_counts[self.rank]
         self._plans = {}
+        # VISTA_A2A_CHUNKS = n > 1 (opt-in, default 1): the temporal block runs on n pixel sub-ranges of the rank's slice in turn and each
+        # sub-range's way back to the frame layout is its own all-to-all, started asynchronously -- the exchange of sub-range i runs under
+        # the compute of sub-range i + 1 (SURVEY 8e "overlap"). Same result bit for bit: the temporal block is pointwise in space.
+        import os
+        self.a2a_chunks = max(1, int(os.environ.get("VISTA_A2A_CHUNKS", "1")))
 
     # global image ids (b*T + t) of this rank's frames, in local (b, t_local) order
     def local_image_ids(self):
@@ -370,6 +377,55 @@ class FrameShard:
         recv = torch.empty(sum(out_splits), dtype=y.dtype, device=y.device)
         self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
         return recv.view(-1, C).index_select(0, pl["unpack_pf"]).view(B * self.t_local, S, C)
+
+    # ---- chunked way back (pixels -> frames) for compute / transport overlap
+    def pixel_chunks(self, S, chunks):
+        """[(lo, hi)] sub-ranges of THIS rank's pixel slice; every rank cuts its own slice by the same rule (split_counts)."""
+        o = offsets(split_counts(self.pixel_counts(S)[self.rank], chunks))
+        return [(o[c], o[c + 1]) for c in range(chunks)]
+
+    def _chunk_plan(self, S, chunks, c, device):
+        key = (S, chunks, c, str(device))
+        pl = self._plans.get(key)
+        if pl is not None:
+            return pl
+        B, P, T, t_l = self.B, self.P, self.T, self.t_local
+        sc = self.pixel_counts(S)
+        so = offsets(sc)
+        sub = [split_counts(sc[q], chunks) for q in range(P)]          # every rank's cut of its own slice
+        cc = [sub[q][c] for q in range(P)]                              # width of sub-range c on rank q
+        co = [offsets(sub[q])[c] for q in range(P)]                     # its offset inside q's slice
+        n_c = cc[self.rank]
+        ar = torch.arange
+        # send: for q, rows (b, t in q's frames, s) of y viewed (B*T*n_c, C)
+        pack = torch.cat([((ar(B)[:, None, None] * T + (self.t_off[q] + ar(self.t_counts[q]))[None, :, None]) * n_c + ar(n_c)[None, None, :]).reshape(-1)
+                          for q in range(P)]) if n_c else torch.empty(0, dtype=torch.int64)
+        # received: for q, rows (b, t_local, s in q's sub-range) -> rows of the frame-sharded result viewed (B*t_l*S, C)
+        dest = torch.cat([((ar(B)[:, None, None] * t_l + ar(t_l)[None, :, None]) * S + (so[q] + co[q] + ar(cc[q]))[None, None, :]).reshape(-1)
+                          for q in range(P)])
+        pl = {"n_c": n_c, "pack": pack.to(device), "dest": dest.to(device),
+              "in_rows": [B * self.t_counts[q] * n_c for q in range(P)], "out_rows": [B * t_l * cc[q] for q in range(P)]}
+        self._plans[key] = pl
+        return pl
+
+    def to_frames_begin(self, y, S, chunks, c):
+        """y: (B*T, n_c, C) -- sub-range c (of `chunks`) of this rank's pixel slice, all frames. Packs it and STARTS its all-to-all towards the
+        frame layout (asynchronously where the transport can); returns the pending exchange for to_frames_end."""
+        n, n_c, C = y.shape
+        pl = self._chunk_plan(S, chunks, c, y.device)
+        assert n == self.B * self.T and n_c == pl["n_c"]
+        send = y.reshape(n * n_c, C).index_select(0, pl["pack"])
+        recv = torch.empty(sum(pl["out_rows"]) * C, dtype=y.dtype, device=y.device)
+        work = self.comm.all_to_all(recv, send.reshape(-1), [r * C for r in pl["out_rows"]], [r * C for r in pl["in_rows"]], async_op=True)
+        return (work, recv, send, pl, C)  # (send is kept alive until the exchange has been waited for)
+
+    def to_frames_end(self, pending, out):
+        """Waits for a to_frames_begin exchange and scatters it into out (B*t_local, S, C)."""
+        work, recv, _send, pl, C = pending
+        if work is not None and hasattr(work, "wait"):
+            work.wait()
+        out.view(-1, C).index_copy_(0, pl["dest"], recv.view(-1, C))
+        return out
 
     def halo_exchange(self, h):
         """Frame-sharded temporal conv support: h (B*t_local, S, C) -> (prev, next), each (B, S, C): the neighbour ranks' last /
