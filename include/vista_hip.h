@@ -115,6 +115,20 @@ typedef struct VkFp8Args {
 int vk_gemm_fp8_mx(const VkGemmDesc* desc, const VkFp8Args* args, void* stream);
 int vk_gemm_fp8_rowstat_parts(const VkGemmDesc* d);
 
+/* Fused FeedForward of the level-0 (width 320) transformers: net = [GEGLU, Dropout, Linear] (vwm/modules/attention.py:85-128) applied as
+ * `x = ff(norm3(x)) + x` (attention.py:524) and as ff_in / ff of the temporal block with its AlphaBlender mix (video_attention.py:119-121,
+ * 137-141) -- ONE kernel, the hidden activation (M x 1280 bf16, 1.18 GB per call at the BASELINE shape) never goes to HBM.
+ *   geglu    : the in-projection exactly as vk_gemm_bf16 would take it (amode DENSE, epi GEGLU: A = x [M][lda], Wt = packed GEGLU weight
+ *              [2 Hd][320], bias, optional folded LayerNorm ln_*); K must be 320. `out` / `ldc` are ignored.
+ *   out_proj : the out-projection as vk_gemm_bf16 would take it (amode DENSE, epi LINEAR, bf16 out: bias, rowvec / rowvec2, res1 / res2,
+ *              alpha / beta, rowstat_out), N = 320, K = Hd (a multiple of 64, <= 1280), with ONE difference: Wt's K axis is permuted inside
+ *              every group of 16 hidden units to [0-3, 8-11, 4-7, 12-15] (the order in which a lane of the in-projection's MFMA
+ *              accumulator holds them, so the hidden values feed the second MFMA straight from registers). `A` / `lda` are ignored.
+ * The hidden activation is rounded to bf16 exactly where the two-kernel form rounds it; rowstat_out gets vk_ff_fused_rowstat_parts()
+ * slabs ([parts][M][2]). Same return codes as vk_gemm_bf16. */
+int vk_ff_fused_bf16(const VkGemmDesc* geglu, const VkGemmDesc* out_proj, void* stream);
+int vk_ff_fused_rowstat_parts(void);
+
 /* GroupNorm(32)[+SiLU] with e4m3 output and ONE scale per image group (of frames_per_group images): y8 = e4m3(y / scale[g]), scale[g] =
  * (max_c |a_c| max|x| + |b_c|) / 448 with y = a_c x + b_c the folded affine form -- an upper bound from the statistics pass (which also
  * tracks max|x|), so no extra pass over the data; a conv output pixel sums taps of its own image only, so the scale factors out of the

@@ -38,7 +38,7 @@ class VkGemmDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 3  # vk_abi_version() of the library this table mirrors
+ABI_VERSION = 4  # vk_abi_version() of the library this table mirrors
 
 # name -> argtypes; every entry returns int. Must list every symbol include/vista_hip.h declares
 # (tests/test_abi.py checks the header against this table and against the built library).
@@ -49,6 +49,8 @@ SIGNATURES = {
     "vk_gemm_fp8": [C.POINTER(VkGemmDesc), _vp, _vp, _i32, _vp],
     "vk_gemm_fp8_mx": [C.POINTER(VkGemmDesc), C.POINTER(VkFp8Args), _vp],
     "vk_gemm_fp8_rowstat_parts": [C.POINTER(VkGemmDesc)],
+    "vk_ff_fused_bf16": [C.POINTER(VkGemmDesc), C.POINTER(VkGemmDesc), _vp],
+    "vk_ff_fused_rowstat_parts": [],
     "vk_layernorm_quant_fp8": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _f32, _vp],
     "vk_groupnorm_silu_fp8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vk_quantize_rows_fp8": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp],

@@ -9,7 +9,7 @@ REPO = os.path.dirname(ROOT)
 CSRC = os.path.join(ROOT, "csrc")
 LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libvista_hip.so")
-SOURCES = ["gemm.hip", "gemm_fp8.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "gemm_fp8.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 
 
 def hipcc():

@@ -92,10 +92,19 @@ def _ln_tuple(norm):
     return (norm.weight, norm.bias, norm.eps)
 
 
-def pack_linear(weight, bias=None, device="cuda", ln=None):
-    """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1]). ln: LayerNorm container applied to the input (folded)."""
-    return _finish_pack(weight.detach().reshape(weight.shape[0], -1).float(), None if bias is None else bias.detach().float(), device,
-                        ln=None if ln is None else _ln_tuple(ln))
+KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+
+def pack_linear(weight, bias=None, device="cuda", ln=None, kperm16=False):
+    """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1]). ln: LayerNorm container applied to the input (folded).
+    kperm16: the out-projection of ff_fused -- K permuted inside every 16-group to KPERM16, the order in which a lane of the
+    in-projection's 32x32 MFMA accumulator holds the hidden units (include/vista_hip.h, vk_ff_fused_bf16)."""
+    w = weight.detach().reshape(weight.shape[0], -1).float()
+    if kperm16:
+        if w.shape[1] % 16:
+            raise ValueError("kperm16 needs K % 16 == 0")
+        w = w.reshape(w.shape[0], -1, 16)[:, :, list(KPERM16)].reshape(w.shape[0], -1)
+    return _finish_pack(w, None if bias is None else bias.detach().float(), device, ln=None if ln is None else _ln_tuple(ln))
 
 
 def pack_rows_as_weight(t, N, K):
@@ -322,6 +331,49 @@ def rowstats(x):
     st = torch.empty((1, M, 2), dtype=F32, device=x.device)
     check(_lib.load().vk_rowstats_bf16(_p(x2), _p(st), M, Cc, ldx, _stream()), "vk_rowstats_bf16")
     return RowStats(st, 1, M)
+
+
+FF_FUSED_WIDTH, FF_FUSED_MAX_HIDDEN = 320, 1280
+FF_FUSED_DBG = 0  # timing experiments only (tools/ff_fused_probe.py): see ff_fused.hip, DBG
+
+
+def ff_fused_ok(pw_in, pw_out):
+    """Shapes vk_ff_fused_bf16 covers: the level-0 FeedForward (width 320, hidden a multiple of 64 up to 1280)."""
+    return (pw_in.geglu and pw_in.K == FF_FUSED_WIDTH and pw_out.N == FF_FUSED_WIDTH and pw_in.N == 2 * pw_out.K
+            and pw_out.K % 64 == 0 and pw_out.K <= FF_FUSED_MAX_HIDDEN)
+
+
+def ff_fused(x, pw_in, pw_out, *, out=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0, rowvec2=None, ln=None,
+             emit_stats=False):
+    """linear(linear(x, pw_in, ln=ln), pw_out', ...epilogue) in ONE kernel (vk_ff_fused_bf16): pw_in = pack_geglu(...), pw_out' =
+    pack_linear(..., kperm16=True). The hidden activation never leaves the CU. Returns out, or (out, RowStats) with emit_stats."""
+    _need(x, BF16, "x")
+    x2d, lda = _rows2d(x, "x")
+    M = x2d.shape[0]
+    if not ff_fused_ok(pw_in, pw_out) or x2d.shape[1] != pw_in.K:
+        raise ValueError("ff_fused: needs a packed GEGLU weight [2H][320] and a kperm16-packed out weight [320][H], H % 64 == 0, H <= 1280")
+    if out is None:
+        out = torch.empty((M, pw_out.N), dtype=BF16, device=x.device)
+    g = VkGemmDesc()
+    g.A, g.lda = _p(x2d), lda
+    g.amode, g.epi = AMODE_DENSE, EPI_GEGLU
+    g.Wt, g.bias, g.M, g.N, g.K = _p(pw_in.wt), _p(pw_in.bias), M, pw_in.N, pw_in.K
+    g.out, g.ldc = _p(out), out.stride(0)   # (ignored by the kernel; validate() wants a non-NULL pointer)
+    g.alpha = 1.0
+    g.tile_cfg = FF_FUSED_DBG
+    _fill_ln(g, pw_in, ln, M)
+    d = VkGemmDesc()
+    d.A, d.lda = _p(x2d), lda               # (ignored)
+    d.amode, d.epi = AMODE_DENSE, EPI_LINEAR
+    _fill_epilogue(d, pw_out, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta, rowvec2)
+    lib = _lib.load()
+    stats = None
+    if emit_stats:
+        parts = lib.vk_ff_fused_rowstat_parts()
+        stats = RowStats(torch.empty((parts, M, 2), dtype=F32, device=x.device), parts, M)
+        d.rowstat_out = _p(stats.t)
+    check(lib.vk_ff_fused_bf16(C.byref(g), C.byref(d), _stream()), "vk_ff_fused_bf16")
+    return (out, stats) if emit_stats else out
 
 
 def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, rowvec=None, res1=None, res2=None, alpha=1.0,
