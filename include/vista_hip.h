@@ -121,9 +121,11 @@ int vk_gemm_fp8_rowstat_parts(const VkGemmDesc* d);
  *   geglu    : the in-projection exactly as vk_gemm_bf16 would take it (amode DENSE, epi GEGLU: A = x [M][lda], Wt = packed GEGLU weight
  *              [2 Hd][320], bias, optional folded LayerNorm ln_*); K must be 320. `out` / `ldc` are ignored.
  *   out_proj : the out-projection as vk_gemm_bf16 would take it (amode DENSE, epi LINEAR, bf16 out: bias, rowvec / rowvec2, res1 / res2,
- *              alpha / beta, rowstat_out), N = 320, K = Hd (a multiple of 64, <= 1280), with ONE difference: Wt's K axis is permuted inside
- *              every group of 16 hidden units to [0-3, 8-11, 4-7, 12-15] (the order in which a lane of the in-projection's MFMA
- *              accumulator holds them, so the hidden values feed the second MFMA straight from registers). `A` / `lda` are ignored.
+ *              alpha / beta, rowstat_out), N = 320, K = Hd (a multiple of 64, 128 <= Hd <= 1280), with ONE difference: Wt's K axis is
+ *              permuted inside every group of 16 hidden units to [0-3, 8-11, 4-7, 12-15] (the order in which a lane of the
+ *              in-projection's MFMA accumulator holds them, so the hidden values feed the second MFMA straight from registers) and the
+ *              matrix is stored chunk-major, bf16 [Hd / 32][320][32] (a 32-wide hidden chunk of all rows = one contiguous 20 KB block;
+ *              bias f32 [320]). `A` / `lda` are ignored.
  * The hidden activation is rounded to bf16 exactly where the two-kernel form rounds it; rowstat_out gets vk_ff_fused_rowstat_parts()
  * slabs ([parts][M][2]). Same return codes as vk_gemm_bf16. */
 int vk_ff_fused_bf16(const VkGemmDesc* geglu, const VkGemmDesc* out_proj, void* stream);

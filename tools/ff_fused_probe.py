@@ -50,7 +50,7 @@ def check(M, C=320, H=1280, ln=True, mode="res"):
     norm = Norm(C) if ln else None
     pin = ops.pack_geglu(w1, b1, ln=norm)
     pout = ops.pack_linear(w2, b2)
-    poutp = ops.pack_linear(w2, b2, kperm16=True)
+    poutp = ops.pack_ff_out(w2, b2)
     st = ops.rowstats(x) if ln else None
     kw = {}
     ref = ref_ff(x, w1, b1, w2, b2, norm)
@@ -106,7 +106,7 @@ def bench(M=460800, C=320, H=1280):
     norm = Norm(C)
     pin = ops.pack_geglu(w1, b1, ln=norm)
     pout = ops.pack_linear(w2, b2)
-    poutp = ops.pack_linear(w2, b2, kperm16=True)
+    poutp = ops.pack_ff_out(w2, b2)
     st = ops.rowstats(x)
     rv2 = rn(50, C, seed=6)
     flop = 2.0 * M * C * (2 * H) + 2.0 * M * H * C
@@ -131,6 +131,18 @@ def bench(M=460800, C=320, H=1280):
         t = min(timeit(lambda: ops.ff_fused(x, pin, poutp, ln=st, out=out, res1=x)) for _ in range(3))
         ops.FF_FUSED_DBG = 0
         print(json.dumps({"case": "fused, timing experiment (wrong results)", "dbg": dbg, "what": what, "ms": round(t, 4)}), flush=True)
+    buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+    ops.FF_FUSED_DBG, ops.FF_FUSED_DBG_BUF = 8, buf
+    ops.ff_fused(x, pin, poutp, ln=st, out=out, res1=x)
+    torch.cuda.synchronize()
+    ops.FF_FUSED_DBG, ops.FF_FUSED_DBG_BUF = 0, None
+    b = buf.view(8, 8).tolist()
+    for w in range(8):
+        n = max(b[w][4] if w < 4 else b[w][2], 1)
+        if w < 4:
+            print(json.dumps({"wave": w, "role": "in", "steps": n, "cycles_per_step": {"mfma": b[w][0] // n, "gelu": b[w][2] // n, "barrier": b[w][3] // n}}), flush=True)
+        else:
+            print(json.dumps({"wave": w, "role": "out", "steps": n, "cycles_per_step": {"dma_issue": b[w][4] // n, "dma+mfma": b[w][0] // n, "barrier": b[w][1] // n}, "epilogue_per_tile": b[w][3] // 15}), flush=True)
     if "--chunks" not in sys.argv:
         return
     # --- Infinity-Cache experiment: the two-kernel form over row chunks (h chunk = rows x 1280 x 2 B)

@@ -55,10 +55,11 @@ class PackedWeight:
     """bf16 [ceil256(N)][K] weight (K contiguous) + f32 bias, laid out for vk_gemm_bf16. `colsum` (f32 [Np]) marks a weight with a
     LayerNorm folded in (pack_*_ln): wt = gamma (.) W, bias = W beta + b, colsum = row sums of the bf16-rounded wt."""
 
-    __slots__ = ("wt", "bias", "N", "K", "geglu", "colsum", "ln_eps")
+    __slots__ = ("wt", "bias", "N", "K", "geglu", "colsum", "ln_eps", "ffout")
 
-    def __init__(self, wt, bias, N, K, geglu=False, colsum=None, ln_eps=0.0):
+    def __init__(self, wt, bias, N, K, geglu=False, colsum=None, ln_eps=0.0, ffout=False):
         self.wt, self.bias, self.N, self.K, self.geglu, self.colsum, self.ln_eps = wt, bias, N, K, geglu, colsum, ln_eps
+        self.ffout = ffout  # laid out for vk_ff_fused_bf16's out-projection (pack_ff_out): not a vk_gemm_bf16 operand
 
 
 def _finish_pack(w2d, bias, device, geglu=False, ln=None):
@@ -95,16 +96,29 @@ def _ln_tuple(norm):
 KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
 
 
-def pack_linear(weight, bias=None, device="cuda", ln=None, kperm16=False):
-    """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1]). ln: LayerNorm container applied to the input (folded).
-    kperm16: the out-projection of ff_fused -- K permuted inside every 16-group to KPERM16, the order in which a lane of the
-    in-projection's 32x32 MFMA accumulator holds the hidden units (include/vista_hip.h, vk_ff_fused_bf16)."""
+def pack_linear(weight, bias=None, device="cuda", ln=None):
+    """nn.Linear.weight [N][K] (or a 1x1 conv weight [N][K][1][1]). ln: LayerNorm container applied to the input (folded)."""
+    return _finish_pack(weight.detach().reshape(weight.shape[0], -1).float(), None if bias is None else bias.detach().float(), device,
+                        ln=None if ln is None else _ln_tuple(ln))
+
+
+def ff_out_layout(w):
+    """[N][K] -> the out-projection operand of vk_ff_fused_bf16 (include/vista_hip.h): K permuted inside every 16-group to KPERM16 (the order in
+    which a lane of the in-projection's 32x32 MFMA accumulator holds the hidden units), then chunk-major [K / 32][N][32] so that a 32-wide
+    hidden chunk of all N rows is one contiguous 20 KB block (whole cache lines per LDS-DMA piece). Pure index shuffle (CPU-testable)."""
+    N, K = w.shape
+    if K % 32:
+        raise ValueError("ff_out_layout needs K % 32 == 0")
+    w = w.reshape(N, K // 16, 16)[:, :, list(KPERM16)].reshape(N, K // 32, 32)
+    return w.permute(1, 0, 2).contiguous().reshape(K // 32 * N, 32)
+
+
+def pack_ff_out(weight, bias=None, device="cuda"):
+    """FeedForward.net[2] weight [N][K] for ops.ff_fused (bf16, ff_out_layout; bias f32)."""
     w = weight.detach().reshape(weight.shape[0], -1).float()
-    if kperm16:
-        if w.shape[1] % 16:
-            raise ValueError("kperm16 needs K % 16 == 0")
-        w = w.reshape(w.shape[0], -1, 16)[:, :, list(KPERM16)].reshape(w.shape[0], -1)
-    return _finish_pack(w, None if bias is None else bias.detach().float(), device, ln=None if ln is None else _ln_tuple(ln))
+    N, K = w.shape
+    b = None if bias is None else bias.detach().to(device=device, dtype=F32).contiguous()
+    return PackedWeight(ff_out_layout(w).to(device=device, dtype=BF16), b, N, K, ffout=True)
 
 
 def pack_rows_as_weight(t, N, K):
@@ -274,6 +288,8 @@ def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=
         k_in += b2d.shape[1]
     if k_in != pw.K:
         raise ValueError(f"linear: K mismatch {k_in} vs {pw.K}")
+    if pw.ffout:
+        raise ValueError("linear: this weight is laid out for ff_fused (pack_ff_out), not for vk_gemm_bf16")
     if pw.geglu:
         nout = pw.N // 2
         if out is None:
@@ -334,24 +350,25 @@ def rowstats(x):
 
 
 FF_FUSED_WIDTH, FF_FUSED_MAX_HIDDEN = 320, 1280
+FF_FUSED_DBG_BUF = None
 FF_FUSED_DBG = 0  # timing experiments only (tools/ff_fused_probe.py): see ff_fused.hip, DBG
 
 
 def ff_fused_ok(pw_in, pw_out):
     """Shapes vk_ff_fused_bf16 covers: the level-0 FeedForward (width 320, hidden a multiple of 64 up to 1280)."""
     return (pw_in.geglu and pw_in.K == FF_FUSED_WIDTH and pw_out.N == FF_FUSED_WIDTH and pw_in.N == 2 * pw_out.K
-            and pw_out.K % 64 == 0 and pw_out.K <= FF_FUSED_MAX_HIDDEN)
+            and pw_out.K % 64 == 0 and 128 <= pw_out.K <= FF_FUSED_MAX_HIDDEN)
 
 
 def ff_fused(x, pw_in, pw_out, *, out=None, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0, rowvec2=None, ln=None,
              emit_stats=False):
     """linear(linear(x, pw_in, ln=ln), pw_out', ...epilogue) in ONE kernel (vk_ff_fused_bf16): pw_in = pack_geglu(...), pw_out' =
-    pack_linear(..., kperm16=True). The hidden activation never leaves the CU. Returns out, or (out, RowStats) with emit_stats."""
+    pack_ff_out(...). The hidden activation never leaves the CU. Returns out, or (out, RowStats) with emit_stats."""
     _need(x, BF16, "x")
     x2d, lda = _rows2d(x, "x")
     M = x2d.shape[0]
-    if not ff_fused_ok(pw_in, pw_out) or x2d.shape[1] != pw_in.K:
-        raise ValueError("ff_fused: needs a packed GEGLU weight [2H][320] and a kperm16-packed out weight [320][H], H % 64 == 0, H <= 1280")
+    if not ff_fused_ok(pw_in, pw_out) or not pw_out.ffout or x2d.shape[1] != pw_in.K:
+        raise ValueError("ff_fused: needs a packed GEGLU weight [2H][320] and a pack_ff_out weight [320][H], H % 64 == 0, 128 <= H <= 1280")
     if out is None:
         out = torch.empty((M, pw_out.N), dtype=BF16, device=x.device)
     g = VkGemmDesc()
@@ -361,6 +378,8 @@ def ff_fused(x, pw_in, pw_out, *, out=None, rowvec=None, rows_per_vec=0, res1=No
     g.out, g.ldc = _p(out), out.stride(0)   # (ignored by the kernel; validate() wants a non-NULL pointer)
     g.alpha = 1.0
     g.tile_cfg = FF_FUSED_DBG
+    if FF_FUSED_DBG == 8 and FF_FUSED_DBG_BUF is not None:
+        g.splitk_ws = _p(FF_FUSED_DBG_BUF)
     _fill_ln(g, pw_in, ln, M)
     d = VkGemmDesc()
     d.A, d.lda = _p(x2d), lda               # (ignored)
