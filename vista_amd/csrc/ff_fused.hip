@@ -114,7 +114,7 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
     };
 
     // DBG & 8: per-phase cycle counts (s_memtime) summed over the tiles of this workgroup, written by lane 0 of every wave of workgroup 0 to
-    // p1.splitk_ws as 8 x int64 per wave: in-projection waves {A, B, C, barrier wait, steps}, out-projection waves {DMA + MFMA, barrier wait, steps, epilogue, DMA issue}
+    // p1.splitk_ws as 8 x int64 per wave: in-projection waves {A, B, C, barrier wait, steps}, out-projection waves {MFMA + DMA, barrier wait, steps, epilogue, MFMA + DMA again}
     long long tacc[5] = {0, 0, 0, 0, 0};
     auto now = [&]() -> long long { return (DBG & 8) ? (long long)__builtin_amdgcn_s_memtime() : 0ll; };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -158,6 +158,7 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
                 char* hs = smem + OFF_H + sl * H_SLOT;
                 bf16x8_t fr[2][5];
                 f32x16_t S[2];
+                float4 vb[2][2][2], vc[2][2][2];   // [fragment][quad][value | gate]: bias / LayerNorm column sums of this lane's 16 gates
                 auto rd1 = [&](const int grp, bf16x8_t (&f)[5]) {   // in-projection MFMA i = 5 grp + n: k-substep i >> 1, fragment i & 1
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
@@ -175,6 +176,16 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
                     if (g < 7) rd1(g + 1, fr[(g + 1) & 1]);
+                    else {   // the gelu phase's per-column vectors, under the last five MFMAs (read at its start they cost four exposed LDS round trips)
+#pragma unroll
+                        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const int np = 2 * FF_HC * j + 32 * cc + 4 * lh + 8 * q;
+                                vb[cc][q][0] = *(const float4*)(vecb + np); vb[cc][q][1] = *(const float4*)(vecb + np + 16);
+                                vc[cc][q][0] = *(const float4*)(vecc + np); vc[cc][q][1] = *(const float4*)(vecc + np + 16);
+                            }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
@@ -193,11 +204,9 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
                 float av[16], gv[16], uv[16];
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    const int np = 2 * FF_HC * j + 32 * cc + 4 * lh;
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        const float4 ba = *(const float4*)(vecb + np + 8 * g), bg = *(const float4*)(vecb + np + 8 * g + 16);
-                        const float4 ca = *(const float4*)(vecc + np + 8 * g), cg = *(const float4*)(vecc + np + 8 * g + 16);
+                        const float4 ba = vb[cc][g][0], bg = vb[cc][g][1], ca = vc[cc][g][0], cg = vc[cc][g][1];
                         const int o = 8 * cc + 4 * g;
                         av[o + 0] = fmaf(rs, S[cc][4 * g + 0], fmaf(nrm, ca.x, ba.x)); av[o + 1] = fmaf(rs, S[cc][4 * g + 1], fmaf(nrm, ca.y, ba.y));
                         av[o + 2] = fmaf(rs, S[cc][4 * g + 2], fmaf(nrm, ca.z, ba.z)); av[o + 3] = fmaf(rs, S[cc][4 * g + 3], fmaf(nrm, ca.w, ba.w));
@@ -274,12 +283,6 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
                         f[n] = *(const bf16x8_t*)(w2s + w2f_off[i / 10] + (i % 10) * 2048);
                     }
                 };
-                // DMA first: its issue slots (60-190 cycles each for the issuing wave) fall into the in-projection wave's bare-MFMA phase
-                if (!(DBG & 1)) {
-#pragma unroll
-                    for (int q = 0; q < 15; ++q) dma_piece(q, q < 10 ? sr : (sr ^ 1), jw1, jw2);
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 const long long tM = now();
                 hf[0] = *(const bf16x8_t*)(hs + h_off[0]);
                 hf[1] = *(const bf16x8_t*)(hs + h_off[1]);
@@ -297,7 +300,15 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (DBG & 8) tacc[4] += tM - tA;
+                // MFMAs first, DMA after: the 20 MFMAs share the matrix pipe with the in-projection wave's 40 while that wave is in its own MFMA
+                // phase (the pipe is the bound there anyway) and are gone before its gelu phase (MFMA and VALU issue of the two waves of a SIMD
+                // add up rather than overlap: 20 late partner MFMAs stretched the gelu phase by 300-750 cycles); the 15 DMA issues (~120 cycles
+                // each for the issuing wave, whatever their spacing or the issuing role -- measured both ways) then run beside the gelu
+                if (!(DBG & 1)) {
+#pragma unroll
+                    for (int q = 0; q < 15; ++q) dma_piece(q, q < 10 ? sr : (sr ^ 1), jw1, jw2);
+                }
+                if (DBG & 8) tacc[4] += now() - tM;
                 const long long tB = now();
                 __syncthreads();
                 if (DBG & 8) { const long long tC = now(); tacc[0] += tB - tA; tacc[1] += tC - tB; tacc[2] += 1; }
