@@ -297,16 +297,18 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
                         const int i = 5 * v2 + n;
                         if (!(DBG & 4)) O[i % 10][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[v2 & 1][n], hf[i / 10], O[i % 10][0], 0, 0, 0);
                         else asm volatile("" :: "v"(fr[v2 & 1][n]), "v"(hf[i / 10]));
+                        // One DMA piece after each of the first 15 MFMAs. Measured alternatives: all 15 pieces first, then the MFMAs (1.43 ms per
+                        // launch against 1.42: the late MFMAs stretch the partner's gelu phase -- MFMA and VALU issue of the two waves of a SIMD
+                        // add up rather than overlap); MFMAs first, then the pieces (1.59: the DMA lands ~1000 cycles after the step's work is
+                        // done); half of the pieces issued by the in-projection waves (1.54: a piece costs its issuing wave ~120 cycles
+                        // wherever it sits, and those waves are the longer role).
+                        if (!(DBG & 1) && i < 15) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            dma_piece(i, i < 10 ? sr : (sr ^ 1), jw1, jw2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-                // MFMAs first, DMA after: the 20 MFMAs share the matrix pipe with the in-projection wave's 40 while that wave is in its own MFMA
-                // phase (the pipe is the bound there anyway) and are gone before its gelu phase (MFMA and VALU issue of the two waves of a SIMD
-                // add up rather than overlap: 20 late partner MFMAs stretched the gelu phase by 300-750 cycles); the 15 DMA issues (~120 cycles
-                // each for the issuing wave, whatever their spacing or the issuing role -- measured both ways) then run beside the gelu
-                if (!(DBG & 1)) {
-#pragma unroll
-                    for (int q = 0; q < 15; ++q) dma_piece(q, q < 10 ? sr : (sr ^ 1), jw1, jw2);
                 }
                 if (DBG & 8) tacc[4] += now() - tM;
                 const long long tB = now();
