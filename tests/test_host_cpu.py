@@ -238,6 +238,34 @@ def test_weight_packing_layouts_on_cpu():
         ops.geglu_perm(24)
 
 
+def test_ff_fused_out_projection_layout_on_cpu():
+    """ops.ff_out_layout / pack_ff_out (the out-projection operand of vk_ff_fused_bf16, include/vista_hip.h): K permuted inside every 16-group to
+    the order in which a lane of the in-projection's 32x32 MFMA accumulator holds the hidden units, then chunk-major [K/32][N][32].
+    Emulates the kernel's dataflow on the host: lane (l31, lh) of a GEGLU fragment holds hidden units 8 g + 4 lh + e (g = 0, 1; e = 0..3) as the
+    8 k-slots i = 4 g + e of MFMA half lh; the weight fragment's k-slot (lh, i) must then hold the SAME hidden unit."""
+    from vista_amd import ops
+    N, K = 320, 128
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K)
+    lay = ops.ff_out_layout(w)
+    assert lay.shape == (K // 32 * N, 32)
+    lay3 = lay.view(K // 32, N, 32)
+    for chunk in range(K // 32):
+        for s in range(2):                      # k-substep (16-group) of the chunk
+            for lh in range(2):
+                for i in range(8):
+                    hidden = 32 * chunk + 16 * s + 8 * (i >> 2) + 4 * lh + (i & 3)   # what the activation lane puts into k-slot (lh, i)
+                    assert torch.equal(lay3[chunk, :, 16 * s + 8 * lh + i], w[:, hidden])
+    # a permutation of the columns: every weight appears exactly once
+    assert sorted(lay.flatten().tolist()) == sorted(w.flatten().tolist())
+    pw = ops.pack_ff_out(torch.randn(N, 1280), torch.randn(N), device="cpu")
+    assert pw.ffout and pw.N == N and pw.K == 1280 and pw.wt.dtype == torch.bfloat16 and pw.wt.numel() == N * 1280 and pw.bias.shape == (N,)
+    pin = ops.pack_geglu(torch.randn(2560, 320), torch.randn(2560), device="cpu")
+    assert ops.ff_fused_ok(pin, pw)
+    assert not ops.ff_fused_ok(ops.pack_geglu(torch.randn(5120, 640), torch.randn(5120), device="cpu"), pw)     # only the width-320 level
+    with pytest.raises(ValueError):
+        ops.ff_out_layout(torch.zeros(320, 48))
+
+
 def test_layernorm_fold_packing_algebra_on_cpu():
     """pack_*(..., ln=norm) must satisfy  LN(x) W^T + b == rstd * (x W'^T - mean * colsum) + bias'  (include/vista_hip.h, VkGemmDesc.ln_*),
     with colsum taken from the bf16-ROUNDED W' so that the mean term cancels exactly in the kernel's epilogue. Pure host check (no launch):

@@ -790,3 +790,97 @@ def test_packed_weights_follow_parameter_versions():
     ref2 = (lambda h: (h[:, :256] * F.gelu(h[:, 256:])) @ (3.0 * sd["inner.0.net.2.weight"].float()).t() + sd["inner.0.net.2.bias"])(
         x.float() @ sd["inner.0.net.0.proj.weight"].float().t() + sd["inner.0.net.0.proj.bias"])
     close(y2, ref2.to(BF16).float(), "FeedForward after Parameter replacement", rtol=3e-2, arel=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ fused FeedForward (level 0)
+class _Norm:
+    def __init__(self, C, seed=7):
+        g = torch.Generator().manual_seed(seed)
+        self.weight = (1 + 0.2 * torch.randn(C, generator=g)).cuda()
+        self.bias = (0.1 * torch.randn(C, generator=g)).cuda()
+        self.eps = 1e-5
+
+
+def _ff_reference(x, w1, b1, w2, b2, norm):
+    """FeedForward.net = [GEGLU, Dropout, Linear] (vwm/modules/attention.py:85-128) in fp32, with the hidden activation rounded to bf16
+    where both kernel forms round it."""
+    xf = x.float()
+    if norm is not None:
+        xf = F.layer_norm(xf, (xf.shape[1],), norm.weight, norm.bias, norm.eps)
+    a, g = (xf @ w1.float().t() + b1).chunk(2, dim=1)
+    return (a * F.gelu(g)).to(BF16).float() @ w2.float().t() + b2
+
+
+@pytest.mark.parametrize("M", [128, 1000, 4173, 33000])   # one tile, ragged, several tiles, more tiles than CUs
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("mode", ["plain", "res", "blend", "rowvec"])
+def test_ff_fused_matches_reference_and_two_kernel_form(M, ln, mode):
+    """vk_ff_fused_bf16 (GEGLU in-projection -> gelu -> out-projection in one launch) against the fp32 reference of the same FeedForward and
+    against the two-GEMM form it replaces, for every epilogue the UNet uses: attention.py:524 (+x, + frame embedding, row sums for the next
+    LayerNorm), video_attention.py:119-121 (ff_in) and :137-141 (AlphaBlender mix: alpha, res2, rowvec2, beta)."""
+    ops = _ops()
+    C, H = 320, 1280
+    x = rnd(M, C)
+    w1 = rnd(2 * H, C, scale=C ** -0.5, seed=1)
+    b1 = rnd(2 * H, seed=2).float() * 0.5
+    w2 = rnd(C, H, scale=H ** -0.5, seed=3)
+    b2 = rnd(C, seed=4).float()
+    norm = _Norm(C) if ln else None
+    pin, pout, pfo = ops.pack_geglu(w1, b1, ln=norm), ops.pack_linear(w2, b2), ops.pack_ff_out(w2, b2)
+    st = ops.rowstats(x) if ln else None
+    ref = _ff_reference(x, w1, b1, w2, b2, norm)
+    kw = {}
+    if mode == "res":
+        kw = dict(res1=x, emit_stats=True)
+        ref = ref + x.float()
+    elif mode == "blend":
+        S = 100
+        xm, rv2 = rnd(M, C, seed=5), rnd((M + S - 1) // S, C, seed=6).float()
+        kw = dict(res1=x, alpha=0.4, res2=xm, rowvec2=rv2, beta=0.6, rows_per_vec=S)
+        ref = 0.4 * (ref + x.float()) + 0.6 * (xm.float() + rv2.repeat_interleave(S, 0)[:M])
+    elif mode == "rowvec":
+        S = 64
+        rv = rnd((M + S - 1) // S, C, seed=8).float()
+        kw = dict(res1=x, rowvec=rv, rows_per_vec=S, emit_stats=True)
+        ref = ref + x.float() + rv.repeat_interleave(S, 0)[:M]
+    two = ops.linear(ops.linear(x, pin, ln=st), pout, **kw)
+    fus = ops.ff_fused(x, pin, pfo, ln=st, **kw)
+    if isinstance(fus, tuple):
+        (two, st2), (fus, stf) = two, fus
+        assert stf.parts == 2 and stf.t.shape == (2, M, 2)
+        s2, sf = st2.t.sum(0), stf.t.sum(0)     # the row sums of the bf16-rounded outputs feed the next LayerNorm fold
+        assert ((s2 - sf).abs().max() / s2.abs().max()).item() < 1e-3
+        o = fus.float()
+        assert torch.allclose(sf[:, 0], o.sum(1), rtol=1e-3, atol=2e-2) and torch.allclose(sf[:, 1], (o * o).sum(1), rtol=1e-3, atol=2e-2)
+    close(fus, ref, f"ff_fused {M} ln={ln} {mode}")
+    # same products, same bf16 rounding of the hidden activation; only the fp32 summation order of the out-projection differs
+    assert ((fus.float() - two.float()).norm() / two.float().norm()).item() < 2e-3
+
+
+def test_ff_fused_other_hidden_width_strided_input_and_refusals():
+    ops = _ops()
+    M, C, H = 777, 320, 640
+    xw = rnd(M, 2 * C)
+    x = xw[:, :C]                                # a strided view (row stride 640): lda != K
+    w1, b1 = rnd(2 * H, C, scale=C ** -0.5, seed=1), rnd(2 * H, seed=2).float()
+    w2, b2 = rnd(C, H, scale=H ** -0.5, seed=3), rnd(C, seed=4).float()
+    out = ops.ff_fused(x, ops.pack_geglu(w1, b1), ops.pack_ff_out(w2, b2), res1=x)
+    close(out, _ff_reference(x, w1, b1, w2, b2, None) + x.float(), "ff_fused H=640, strided x")
+    with pytest.raises(ValueError):              # a vk_gemm_bf16 weight is not a fused-kernel operand and vice versa
+        ops.ff_fused(x, ops.pack_geglu(w1, b1), ops.pack_linear(w2, b2))
+    with pytest.raises(ValueError):
+        ops.linear(rnd(M, H), ops.pack_ff_out(w2, b2))
+    with pytest.raises(ValueError):              # width 640: not covered
+        ops.ff_fused(rnd(M, 640), ops.pack_geglu(rnd(5120, 640), rnd(5120).float()), ops.pack_ff_out(rnd(640, 2560), None))
+
+
+def test_ff_fused_is_bitwise_repeatable_and_batch_independent():
+    ops = _ops()
+    C, H = 320, 1280
+    x = rnd(3000, C)
+    pin, pfo = ops.pack_geglu(rnd(2 * H, C, scale=C ** -0.5, seed=1), rnd(2 * H, seed=2).float()), ops.pack_ff_out(rnd(C, H, scale=H ** -0.5, seed=3), None)
+    a = ops.ff_fused(x, pin, pfo, res1=x)
+    b = ops.ff_fused(x, pin, pfo, res1=x)
+    assert torch.equal(a, b)
+    c = ops.ff_fused(x[1280:2560], pin, pfo, res1=x[1280:2560])   # rows are independent: a sub-range computes the same bits
+    assert torch.equal(a[1280:2560], c)

@@ -119,6 +119,7 @@ FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1", "conv": os.enviro
        "attention": os.environ.get("VISTA_FP8_ATTN", "0") == "1", "proj": os.environ.get("VISTA_FP8_PROJ", "0") == "1"}
 
 
+FF_FUSED = os.environ.get("VISTA_FF_FUSED", "1") != "0"    # A/B hook: 0 = the level-0 FeedForward as two GEMM launches (rounds 1-3)
 QKV_SPLIT = os.environ.get("VISTA_QKV_SPLIT", "0") == "1"  # A/B hook: spatial self-attention's projections as in round 2 (q|k + V^T GEMMs)
 Q_LOG2 = os.environ.get("VISTA_ATTN_QLOG2", "1") != "0"   # A/B hook: 0 = unscaled query rows + the scale applied inside the attention kernel
 
@@ -139,7 +140,13 @@ class FeedForward(nn.Module, Packable):
     def _pack(self, dev):
         # "in" (the UNFOLDED GEGLU weight) is packed on first use by forward(): the UNet path only runs forward_folded, whose LN-folded
         # copy belongs to the owning block -- packing both would keep ~0.6 GB of dead bf16 weights on the device for the 1.65 B network
-        pk = {"out": ops.pack_linear(self.net[2].weight, self.net[2].bias, dev)}
+        w2 = self.net[2].weight
+        if FF_FUSED and not FP8["feedforward"] and w2.shape[0] == ops.FF_FUSED_WIDTH and w2.shape[1] % 64 == 0 and 128 <= w2.shape[1] <= ops.FF_FUSED_MAX_HIDDEN:
+            # level-0 FeedForward (width 320): GEGLU + out-projection as ONE kernel (vk_ff_fused_bf16); its out-projection operand has its own
+            # layout (K permuted to the MFMA accumulator order, chunk-major), so the plain "out" pack is not built
+            pk = {"out_fused": ops.pack_ff_out(w2, self.net[2].bias, dev)}
+        else:
+            pk = {"out": ops.pack_linear(w2, self.net[2].bias, dev)}
         if FP8["feedforward"]:
             pk["in8"] = ops.pack_geglu_fp8(self.net[0].proj.weight, self.net[0].proj.bias, dev)
             pk["out8"] = ops.pack_linear_fp8(self.net[2].weight, self.net[2].bias, dev)
@@ -156,6 +163,8 @@ class FeedForward(nn.Module, Packable):
         if not FP8["feedforward"]:
             if "in" not in pk:  # lives in the pack dict, so it is dropped with it whenever the parameters change
                 pk["in"] = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight.device)
+            if "out_fused" in pk:
+                return ops.ff_fused(y, pk["in"], pk["out_fused"], **epilogue)
             return ops.linear(ops.linear(y, pk["in"]), pk["out"], **epilogue)
         if "in8" not in pk:  # the switch was flipped after the bf16 pack was built
             self.invalidate_packed()
@@ -179,7 +188,10 @@ class FeedForward(nn.Module, Packable):
             yq, ys = ops.layernorm_quant_fp8(x, norm)
             h8, hs = ops.linear_fp8(yq, ys, pk["in8"], mx_out=True)
             return ops.linear_fp8(h8, None, pk["out8"], a_mx=hs, **epilogue)
-        return ops.linear(ops.linear(x, pw_in, ln=stats), self.packed()["out"], **epilogue)
+        pk = self.packed()
+        if "out_fused" in pk:
+            return ops.ff_fused(x, pw_in, pk["out_fused"], ln=stats, **epilogue)
+        return ops.linear(ops.linear(x, pw_in, ln=stats), pk["out"], **epilogue)
 
 
 class MemoryEfficientCrossAttention(nn.Module, Packable):
