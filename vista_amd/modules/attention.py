@@ -140,17 +140,25 @@ class FeedForward(nn.Module, Packable):
     def _pack(self, dev):
         # "in" (the UNFOLDED GEGLU weight) is packed on first use by forward(): the UNet path only runs forward_folded, whose LN-folded
         # copy belongs to the owning block -- packing both would keep ~0.6 GB of dead bf16 weights on the device for the 1.65 B network
-        w2 = self.net[2].weight
-        if FF_FUSED and not FP8["feedforward"] and w2.shape[0] == ops.FF_FUSED_WIDTH and w2.shape[1] % 64 == 0 and 128 <= w2.shape[1] <= ops.FF_FUSED_MAX_HIDDEN:
-            # level-0 FeedForward (width 320): GEGLU + out-projection as ONE kernel (vk_ff_fused_bf16); its out-projection operand has its own
-            # layout (K permuted to the MFMA accumulator order, chunk-major), so the plain "out" pack is not built
-            pk = {"out_fused": ops.pack_ff_out(w2, self.net[2].bias, dev)}
-        else:
-            pk = {"out": ops.pack_linear(w2, self.net[2].bias, dev)}
+        # the bf16 out-projection operand is packed on first use as well (_out_pack): plain for vk_gemm_bf16, or -- level 0, width 320 -- in the
+        # fused kernel's own layout; whichever form the switches select at call time, so that flipping them restores the other path bit for bit
+        pk = {}
         if FP8["feedforward"]:
             pk["in8"] = ops.pack_geglu_fp8(self.net[0].proj.weight, self.net[0].proj.bias, dev)
             pk["out8"] = ops.pack_linear_fp8(self.net[2].weight, self.net[2].bias, dev)
         return pk
+
+    def _out_pack(self, pk):
+        """(fused?, packed out-projection) for the bf16 path. Level-0 FeedForward (width 320): GEGLU + out-projection run as ONE kernel
+        (vk_ff_fused_bf16), whose out-projection operand has its own layout (K permuted to the MFMA accumulator order, chunk-major)."""
+        w2 = self.net[2].weight
+        if FF_FUSED and w2.shape[0] == ops.FF_FUSED_WIDTH and w2.shape[1] % 64 == 0 and 128 <= w2.shape[1] <= ops.FF_FUSED_MAX_HIDDEN:
+            if "out_fused" not in pk:
+                pk["out_fused"] = ops.pack_ff_out(w2, self.net[2].bias, w2.device)
+            return True, pk["out_fused"]
+        if "out" not in pk:
+            pk["out"] = ops.pack_linear(w2, self.net[2].bias, w2.device)
+        return False, pk["out"]
 
     def pack_in_folded(self, norm, dev):
         """GEGLU in-projection with the preceding LayerNorm `norm` folded in (the owner block packs it: it owns the norm)."""
@@ -163,9 +171,10 @@ class FeedForward(nn.Module, Packable):
         if not FP8["feedforward"]:
             if "in" not in pk:  # lives in the pack dict, so it is dropped with it whenever the parameters change
                 pk["in"] = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight.device)
-            if "out_fused" in pk:
-                return ops.ff_fused(y, pk["in"], pk["out_fused"], **epilogue)
-            return ops.linear(ops.linear(y, pk["in"]), pk["out"], **epilogue)
+            fused, pw_out = self._out_pack(pk)
+            if fused:
+                return ops.ff_fused(y, pk["in"], pw_out, **epilogue)
+            return ops.linear(ops.linear(y, pk["in"]), pw_out, **epilogue)
         if "in8" not in pk:  # the switch was flipped after the bf16 pack was built
             self.invalidate_packed()
             pk = self.packed()
@@ -188,10 +197,10 @@ class FeedForward(nn.Module, Packable):
             yq, ys = ops.layernorm_quant_fp8(x, norm)
             h8, hs = ops.linear_fp8(yq, ys, pk["in8"], mx_out=True)
             return ops.linear_fp8(h8, None, pk["out8"], a_mx=hs, **epilogue)
-        pk = self.packed()
-        if "out_fused" in pk:
-            return ops.ff_fused(x, pw_in, pk["out_fused"], ln=stats, **epilogue)
-        return ops.linear(ops.linear(x, pw_in, ln=stats), pk["out"], **epilogue)
+        fused, pw_out = self._out_pack(self.packed())
+        if fused:
+            return ops.ff_fused(x, pw_in, pw_out, ln=stats, **epilogue)
+        return ops.linear(ops.linear(x, pw_in, ln=stats), pw_out, **epilogue)
 
 
 class MemoryEfficientCrossAttention(nn.Module, Packable):
