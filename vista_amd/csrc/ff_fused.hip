@@ -227,10 +227,10 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
                 for (int i = 0; i < 16; ++i) uv[i] = (DBG & 2) ? uv[i] : __builtin_amdgcn_exp2f(uv[i]);
                 FF_PIN16(uv);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { av[i] *= gv[i]; uv[i] = 1.f + uv[i]; }
+                for (int i = 0; i < 16; ++i) uv[i] = 1.f + uv[i];
                 FF_PIN16(uv);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) uv[i] = (DBG & 2) ? uv[i] : __builtin_amdgcn_rcpf(uv[i]);
+                for (int i = 0; i < 16; ++i) uv[i] = gv[i] * ((DBG & 2) ? uv[i] : __builtin_amdgcn_rcpf(uv[i]));   // = gelu_erf_f(gv[i]), operation for operation
                 FF_PIN16(uv);
 #undef FF_PIN16
 #pragma unroll
