@@ -52,63 +52,57 @@ def build_model(model_channels, seed=0):
     return net.eval()
 
 
-def cpu_baseline(net, T, sample_hw, seed):
-    """CPU leg, on the host cores, bounded to ~30 s: (a) ONE CFG UNet forward (N = 2T images, full-width weights) at a reduced latent
-    through the fp32 oracle restatement of the reference (oracle/vista_oracle.py) -- or through the reference's own VideoUNet
-    (oracle/ref_shim.py) where /root/reference is mounted -- with its FLOPs counted by torch's flop counter; (b) the spatial
-    self-attention core at the FULL 9216-token level for one image (5 heads), because attention cost is quadratic in the tokens and a
-    FLOP-ratio extrapolation from a 512-token sample alone would understate it. The full-size step is then estimated as
-    attention FLOPs / rate(b) + remaining FLOPs / rate(a). Also returns the GPU-vs-oracle parity at the sample."""
+def cpu_baseline(net, T, H, W, seed):
+    """CPU leg, on the host cores of the GPU box, bounded to about a minute: two REAL full-size pieces of the timed step run through the fp32 CPU
+    restatement of the reference (oracle/vista_oracle.py, pinned to the reference's own modules at <= 2e-4 of output rms by
+    tests/test_oracle_cpu.py; /root/reference does not exist on the GPU box, so kind is always "port"), with the network's own weights, one clip
+    (T frames) of the CFG pair each, at the full 72x128 latent:
+      (a) the first level-0 SpatialVideoTransformer (input_blocks.1.1: width 320, 9216 tokens per frame: spatial + temporal transformer block),
+      (b) the first level-0 VideoResBlock (input_blocks.1.0: 2-D ResBlock + 3x1x1 temporal ResBlock + blend).
+    Their FLOPs are counted by torch's flop counter. The level-0 transformers and ResBlocks are ~60 % of the step's FLOPs; the whole step is
+    estimated as (step FLOPs) / (blended rate of the two pieces). Nothing is read from earlier rounds' files. Also returns the HIP path's
+    relative L2 error against the oracle on both pieces (the same modules of the timed network, same inputs)."""
     from torch.utils.flop_counter import FlopCounterMode
-    from oracle import ref_shim, vista_oracle as O
-    from oracle.make_golden import unet_inputs
-    h, w = sample_hw
-    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
-    x8, ts, ctx, y, mask = unet_inputs(T, h, w, seed=seed, sigma=7.0)
+    from oracle import vista_oracle as O
+    from vista_amd import ops, synth
     cores = torch.get_num_threads()
-    kind = "port"
-    fwd = lambda: O.unet_forward(sd, x8, ts, ctx, y, mask, T)  # noqa: E731
-    if ref_shim.available():  # build container only: time the reference's own modules
-        ref_net = ref_shim.build_ref_unet(**ref_shim.unet_kwargs(net.model_channels))
-        ref_net.load_state_dict(sd, strict=True)
-        kind = "reference"
-        fwd = lambda: ref_net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=T)  # noqa: E731
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731  (inputs representable in the HIP path's storage type)
+    x = bf(torch.randn(T, 320, H, W, generator=g))
+    emb = bf(torch.randn(T, 1280, generator=g) * 0.7)
+    w = synth.window_inputs(T=T, H=2, W=2, seed=seed, trajectory=[0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2])
+    ctx = bf(w["c"]["crossattn"])   # (T, 1, 3456): CLIP-like token + action sinusoids
+    pieces = {}
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(T, H * W, -1).to(torch.bfloat16).cuda().contiguous()  # noqa: E731
+    nchw = lambda t: t.float().cpu().view(T, H, W, -1).permute(0, 3, 1, 2)  # noqa: E731
+    rel = lambda a, r: ((a - r).pow(2).sum().sqrt() / r.pow(2).sum().sqrt()).item()  # noqa: E731
     with torch.no_grad():
-        with FlopCounterMode(display=False) as fc:
-            t0 = time.perf_counter()
-            ref = fwd()
-            dt = time.perf_counter() - t0
-        flops = float(fc.get_total_flops())
-        # (b) full-size level-0 attention core, one image: softmax(q k^T / 8) v over 9216 tokens x 5 heads
-        S0 = 72 * 128
-        g = torch.Generator().manual_seed(seed)
-        q, k, v = (torch.randn(5, S0, 64, generator=g) for _ in range(3))
-        t0 = time.perf_counter()
-        s = torch.matmul(q, k.transpose(-1, -2)) * 0.125
-        torch.matmul(torch.softmax(s, dim=-1), v)
-        dt_attn = time.perf_counter() - t0
-        del s
-    attn_rate = 4.0 * 5 * S0 * S0 * 64 / dt_attn
-    out = net(x8.cuda(), timesteps=ts.cuda(), context=ctx.cuda(), y=y.cuda(), cond_mask=mask.cuda(), num_frames=T).cpu()
-    rel = ((out - ref).pow(2).sum().sqrt() / ref.pow(2).sum().sqrt()).item()
-    est_s = FLOP_ATTN_PER_STEP / attn_rate + (FLOP_PER_STEP_CFG - FLOP_ATTN_PER_STEP) / (flops / dt)
-    # Anchor of the extrapolation: ONE real full-size forward of the same port (N = 25 images, 25x72x128, 1.65 B weights) on a GPU box's host
-    # cores, measured by tools/full_size_parity.py (353 s: too long for the default bench run, so it is read from the committed record).
-    anchor = None
-    ap_ = os.path.join(ROOT, "profiles", "r02_full_size_parity.json")
-    if os.path.exists(ap_):
-        a = json.load(open(ap_))
-        anchor = {"full_size_forward_s": a["oracle_seconds_on_host"], "n_img": 25, "host_threads": a["host_threads"],
-                  "implied_cfg_step_s": 2.0 * a["oracle_seconds_on_host"], "source": "profiles/r02_full_size_parity.json (tools/full_size_parity.py)"}
-    return {"value": 1.0 / est_s, "unit": "steps/s", "cores": cores, "kind": kind,
-            "sample": f"EXTRAPOLATED from a bounded sample: (a) 1 CFG UNet forward (N={2*T} images, full-width 1.65B weights) at latent {h}x{w} on the host: {dt:.1f} s, "
-                      f"{flops/1e12:.2f} TFLOP counted -> {flops/dt/1e12:.3f} TFLOP/s; (b) level-0 spatial attention core at the full 9216 tokens, "
-                      f"1 image x 5 heads: {dt_attn:.2f} s -> {attn_rate/1e12:.3f} TFLOP/s; full-size step estimated as 3.10e13 attention FLOP at (b) + "
-                      f"1.294e14 other FLOP at (a) = {est_s:.0f} s/step. kind 'port' = oracle/vista_oracle.py, the fp32 restatement pinned to the "
-                      "reference's own modules at <= 2e-4 of output rms (tests/test_oracle_cpu.py); 'reference' = those modules themselves, "
-                      "only where /root/reference is mounted",
-            "full_size_anchor": anchor,
-            "parity_rel_l2_at_sample": rel}
+        for name, fn in (("level-0 SpatialVideoTransformer (input_blocks.1.1)", lambda: O.spatial_video_transformer(sd, "input_blocks.1.1", x, ctx, T, True)),
+                         ("level-0 VideoResBlock (input_blocks.1.0)", lambda: O.video_resblock(sd, "input_blocks.1.0", x, emb, T))):
+            with FlopCounterMode(display=False) as fc:
+                t0 = time.perf_counter()
+                ref = fn()
+                dt = time.perf_counter() - t0
+            pieces[name] = {"seconds": dt, "flop": float(fc.get_total_flops()), "ref": ref}
+        frame_idx = torch.arange(T, dtype=torch.float32).cuda()
+        out_a = net.input_blocks[1][1](tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W)
+        out_b = net.input_blocks[1][0](tok(x), torch.nn.functional.silu(emb).to(torch.bfloat16).cuda(), T, H, W)
+    (na, pa), (nb, pb) = pieces.items()
+    parity = {na: rel(nchw(out_a), pa["ref"]), nb: rel(nchw(out_b), pb["ref"])}
+    f_meas = pa["flop"] + pb["flop"]
+    t_meas = pa["seconds"] + pb["seconds"]
+    rate = f_meas / t_meas
+    est_s = FLOP_PER_STEP_CFG / rate
+    share = 2 * 5 * f_meas / FLOP_PER_STEP_CFG   # 2 clips x 5 level-0 (transformer, ResBlock) pairs per forward
+    return {"value": 1.0 / est_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"two full-size pieces of the step timed in this run on the host ({cores} threads), one 25-frame clip each at latent {H}x{W}, network weights: "
+                      f"{na}: {pa['seconds']:.1f} s, {pa['flop'] / 1e12:.2f} TFLOP; {nb}: {pb['seconds']:.1f} s, {pb['flop'] / 1e12:.2f} TFLOP -> "
+                      f"{rate / 1e12:.3f} TFLOP/s blended; the step's 10 such pairs are {100 * share:.0f} % of its {FLOP_PER_STEP_CFG:.3e} FLOP; "
+                      f"whole step EXTRAPOLATED at the blended rate: {est_s:.0f} s/step. kind 'port' = oracle/vista_oracle.py (fp32 restatement of the "
+                      "reference, pinned to the reference's own modules by tests/test_oracle_cpu.py)",
+            "measured": {"seconds": t_meas, "flop": f_meas, "share_of_step_flop": share},
+            "parity_rel_l2_hip_vs_oracle": parity}
 
 
 def spawn_ranks(n):
@@ -203,7 +197,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side figures (IdentityGuider N=25, GEMM rooflines, config-3 layout)")
     ap.add_argument("--shard", choices=["hybrid", "frames"], default="hybrid")
-    ap.add_argument("--cpu-sample", type=str, default="16x32")
     ap.add_argument("--plumbing-only", action="store_true", help="N > 1: rendezvous + partition/exchange check on the host, no GPU work")
     ap.add_argument("--graph", action="store_true", help="replay every step's UNet forward from one captured hipGraph (FusedLoop(graph=True)); the "
                     "level-0 attention launches of the roofline object are then timed on one extra eager step outside the timed region")
@@ -433,8 +426,7 @@ def main():
                 finally:
                     _att.FP8.update(saved)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
-        h, wd = (int(v) for v in args.cpu_sample.split("x"))
-        res["cpu_baseline"] = cpu_baseline(net, T, (h, wd), seed=1)
+        res["cpu_baseline"] = cpu_baseline(net, T, H, W, seed=1) if full else None
     else:
         res["cpu_baseline"] = None
     if rank == 0:
