@@ -531,7 +531,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 
 inline int validate(const VkGemmDesc* d) {
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 5 || d->tile_cfg > 7) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 6 || d->tile_cfg > 7) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;
@@ -555,11 +555,21 @@ inline int validate(const VkGemmDesc* d) {
 
 }  // namespace
 
+// gemm_stream.hip: the weight-stationary streaming kernel for the level-0 K = 320 projections (0 = does not take this problem)
+extern "C" int vk_gemm_stream_fit(const VkGemmDesc* d);
+extern "C" int vk_gemm_stream_launch(const VkGemmDesc* d, void* stream);
+static int stream_fit(const VkGemmDesc* d) {
+    static const bool on = [] { const char* e = getenv("VISTA_GEMM_STREAM"); return !e || atoi(e) != 0; }();   // A/B hook: 0 = tiled kernels only
+    return (on || (d->tile_cfg & 7) == 6) ? vk_gemm_stream_fit(d) : 0;
+}
+
 extern "C" int vk_gemm_rowstat_parts(const VkGemmDesc* d) {
     const int rc = validate(d);
     if (rc != VK_OK) return rc;
     if (d->epi != EPI_LINEAR || d->out_f32) return VK_EINVAL;
+    if (const int fit = stream_fit(d)) return d->N / (32 * fit);  // one slab per column tile: the workgroup combines its waves' row sums
     VkGemmDesc q = *d;
+    if ((q.tile_cfg & 7) == 6) q.tile_cfg &= ~7;
     q.rowstat_out = (float*)1;  // what the launcher will see: never split-K
     const TileChoice t = choose_tile(&q);
     int bn, wn;
@@ -572,14 +582,21 @@ extern "C" int vk_gemm_rowstat_parts(const VkGemmDesc* d) {
 extern "C" int vk_gemm_tile_choice(const VkGemmDesc* d) {
     const int rc = validate(d);
     if (rc != VK_OK) return rc;
-    const TileChoice t = choose_tile(d);
+    if (stream_fit(d)) return 6 * 16 + 1;
+    VkGemmDesc q = *d;
+    if ((q.tile_cfg & 7) == 6) q.tile_cfg &= ~7;
+    const TileChoice t = choose_tile(&q);
     return t.cfg * 16 + t.ksplit;
 }
 
-extern "C" int vk_gemm_bf16(const VkGemmDesc* d, void* stream_) {
+extern "C" int vk_gemm_bf16(const VkGemmDesc* d_in, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    const int rc = validate(d);
+    const int rc = validate(d_in);
     if (rc != VK_OK) return rc;
+    if (stream_fit(d_in)) return vk_gemm_stream_launch(d_in, stream_);
+    VkGemmDesc dq = *d_in;
+    if ((dq.tile_cfg & 7) == 6) dq.tile_cfg &= ~7;   // streaming variant requested for a problem it does not take: the launcher's own choice
+    const VkGemmDesc* d = &dq;
     const bool f32 = d->out_f32 != 0;
     switch (d->epi) {
         case EPI_LINEAR:
