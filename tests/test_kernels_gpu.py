@@ -5,6 +5,7 @@ the kernel's bf16 output rounding + fp32 accumulation order.  Tolerance (stated)
 (bf16 has 8 bits of mantissa: 2^-8 = 3.9e-3 relative per rounding; attention adds the bf16 rounding of P).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -884,3 +885,75 @@ def test_ff_fused_is_bitwise_repeatable_and_batch_independent():
     assert torch.equal(a, b)
     c = ops.ff_fused(x[1280:2560], pin, pfo, res1=x[1280:2560])   # rows are independent: a sub-range computes the same bits
     assert torch.equal(a[1280:2560], c)
+
+
+# ------------------------------------------------------------------------------------------------ weight-stationary streaming GEMM (level-0 K = 320 projections)
+@pytest.mark.parametrize("M,S", [(32 * 300 + 7, 288), (70016, 9216 // 4)])   # ragged last tile; more row tiles than workgroups
+@pytest.mark.parametrize("kind", ["plain", "res", "stats", "res+rowvec+stats", "qkv_lnfold", "n640"])
+def test_gemm_stream_forced_matches_reference_and_tiled_kernel(M, S, kind):
+    """gemm_stream.hip (VkGemmDesc.tile_cfg = 6: weights in registers, activations / residual / LayerNorm statistics through LDS-DMA rings
+    with counted vmcnt waits) for every epilogue it supports, against torch fp32 and against the tiled kernel (bitwise: same accumulation
+    order, same epilogue arithmetic). Reference call sites: attention.py:344-346 (q|k|v), :421 (to_out), :579,602 (proj_in / proj_out)."""
+    ops = _ops()
+    C = 320
+    x = rnd(M, C)
+    res = rnd(M, C, seed=3)
+    kw, ln, N = {}, None, C
+    if kind == "qkv_lnfold":
+        N = 3 * C
+    elif kind == "n640":
+        N = 2 * C
+    w, b = rnd(N, C, scale=C ** -0.5, seed=1), rnd(N, seed=2).float()
+    ref = x.float() @ w.float().t() + b
+    if kind == "qkv_lnfold":
+        nrm = _Norm(C)
+        ln = ops.rowstats(x)
+        pw = ops.pack_linear(w, b, ln=nrm)
+        ref = F.layer_norm(x.float(), (C,), nrm.weight, nrm.bias, nrm.eps) @ w.float().t() + b
+    else:
+        pw = ops.pack_linear(w, b)
+    if kind in ("res", "res+rowvec+stats"):
+        kw["res1"] = res
+        ref = ref + res.float()
+    if kind == "res+rowvec+stats":
+        rv = rnd((M + S - 1) // S, C, seed=5).float()
+        kw.update(rowvec=rv, rows_per_vec=S)
+        ref = ref + rv.repeat_interleave(S, 0)[:M]
+    if "stats" in kind:
+        kw["emit_stats"] = True
+    outs = {}
+    for cfg in (6, 4):
+        ops.TILE_CFG = cfg
+        try:
+            outs[cfg] = ops.linear(x, pw, ln=ln, **kw)
+        finally:
+            ops.TILE_CFG = 0
+    o6, o4 = outs[6], outs[4]
+    if "stats" in kind:
+        (o6, s6), (o4, s4) = o6, o4
+        assert s6.parts == 1, "the streaming kernel combines its waves' row sums into one slab"
+        of = o6.float()
+        assert torch.allclose(s6.t[0, :, 0], of.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(s6.t[0, :, 1], (of * of).sum(1), rtol=1e-4, atol=1e-2)
+    close(o6, ref, f"gemm_stream {kind} M={M}")
+    assert torch.equal(o6, o4), "streaming and tiled kernels must agree bit for bit"
+
+
+def test_gemm_stream_is_chosen_where_it_wins_and_only_there():
+    """The launcher's rule (vk_gemm_tile_choice: variant * 16 + K slices): N = 320 + residual at BASELINE size -> variant 6; anything else stays tiled."""
+    import ctypes as C
+    ops = _ops()
+    lib = ops._lib.load()
+    x = rnd(65536 * 2, 320)
+    pw = ops.pack_linear(rnd(320, 320, seed=1), rnd(320, seed=2).float())
+    out = torch.empty_like(x)
+
+    def choice(**kw):
+        d = ops.VkGemmDesc()
+        d.A, d.lda, d.amode, d.epi = ops._p(x), 320, 0, 0
+        ops._fill_epilogue(d, pw, out, x.shape[0], kw.get("rowvec"), kw.get("rows_per_vec", 0), kw.get("res1"), None, 1.0, 0.0)
+        if kw.get("stats"):
+            d.rowstat_out = ops._p(torch.empty(4, device="cuda"))
+        return lib.vk_gemm_tile_choice(C.byref(d)) // 16
+    if os.environ.get("VISTA_GEMM_STREAM", "1") != "0":
+        assert choice(res1=x) == 6
+    assert choice() != 6 and choice(res1=x, stats=True) != 6
