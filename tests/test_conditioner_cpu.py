@@ -71,6 +71,34 @@ def test_general_conditioner_routing_matches_reference_golden():
     assert float(uc["crossattn"].abs().max()) == 0.0 and float(uc["concat"].abs().max()) == 0.0 and torch.equal(uc["vector"], c["vector"])
 
 
+def test_general_conditioner_accepts_training_ucg_rates_like_the_reference():
+    """the reference's training YAMLs set ucg_rate 0.15 / legacy_ucg_value on embedders (encoders/modules.py:85-104); they must
+    instantiate here, sampling (get_unconditional_conditioning) must run with the dropout disabled and restore the rates (:172-180), and a
+    bare forward() -- where the reference would apply training dropout -- must refuse rather than silently skip it."""
+    from oracle import cond_fixture as CF
+    from vista_amd.modules.encoders.modules import GeneralConditioner
+    _stub_module()
+    cfgs = CF.emb_models("cond_stub_v")
+    for c in cfgs:
+        if c["target"].endswith("ConcatTimestepEmbedderND"):
+            c["target"] = "cond_stub_v.TorchConcatTimestepEmbedderND"
+    plain = GeneralConditioner([dict(c) for c in cfgs])
+    cfgs[0]["ucg_rate"] = 0.15
+    cfgs[1]["ucg_rate"] = 0.15
+    cfgs[1]["legacy_ucg_value"] = None
+    cond = GeneralConditioner(cfgs)
+    assert [e.ucg_rate for e in cond.embedders][:2] == [0.15, 0.15]
+    g = torch.load(os.path.join(GOLD, "cond_general.pt"))
+    batch = {k: v for k, v in g["batch"].items()} if "batch" in g else None
+    if batch is not None:
+        c1, u1 = cond.get_unconditional_conditioning(batch, force_uc_zero_embeddings=["cond_frames"])
+        c0, u0 = plain.get_unconditional_conditioning(batch, force_uc_zero_embeddings=["cond_frames"])
+        assert all(torch.equal(c1[k], c0[k]) and torch.equal(u1[k], u0[k]) for k in c0)
+        with pytest.raises(NotImplementedError):
+            cond(batch)
+    assert [e.ucg_rate for e in cond.embedders][:2] == [0.15, 0.15], "rates restored after sampling"
+
+
 def test_conditioner_config_of_the_reference_instantiates_this_package():
     """configs/inference/vista.yaml's conditioner_config (vwm.* targets) builds vista_amd classes with the reference's state-dict names."""
     import yaml

@@ -318,6 +318,24 @@ def test_hipgraph_replay_of_the_unet_forward_is_bitwise_the_eager_loop(monkeypat
     assert made and made[-1]._graph is not None and "graph" in made[-1]._graph, "the graph path did not run"
     assert torch.equal(graphed, eager)
     assert torch.equal(run_50_step(net, w, T, 10), eager)
+    # the captured graph is cached on the UNet and shared by later FusedLoops of the same geometry (one capture, one warm-up
+    # stream, one split-K workspace per device) ...
+    assert len(made) >= 2 and made[-1]._graph is made[-2]._graph and len(net.__dict__["_hipgraph_cache"]) == 1
+    from vista_amd import ops
+    assert len(FusedLoop._WARM_STREAMS) == 1 and len(ops._GRAPH_WS) == 1
+    # ... with the conditioning as static buffers: another window through the SAME graph equals its own eager run
+    w2 = dict(w)
+    w2["c"] = {k: (v * 0.5 if k == "crossattn" else v) for k, v in w["c"].items()}
+    monkeypatch.setenv("VISTA_HIPGRAPH", "0")
+    eager2 = run_50_step(net, w2, T, 4)
+    monkeypatch.setenv("VISTA_HIPGRAPH", "1")
+    assert torch.equal(run_50_step(net, w2, T, 4), eager2) and not torch.equal(eager2, run_50_step(net, w, T, 4))
+    # ... and dropped when a parameter changes after the capture (its launches point at the old packed weights)
+    with torch.no_grad():
+        next(net.parameters()).mul_(1.0)
+    g_old = made[-1]._graph
+    run_50_step(net, w, T, 2)
+    assert made[-1]._graph is not g_old
 
 
 def _window_only():

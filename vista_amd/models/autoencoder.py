@@ -62,6 +62,14 @@ class AutoencoderKLModeOnly(nn.Module):
         self.quant_conv = ConvNd(zc * ddconfig["z_channels"], zc * embed_dim, (1, 1))
         self.embed_dim, self.double_z = embed_dim, bool(ddconfig.get("double_z", True))
         self._pk, self._pk_key = None, None
+        # any load_state_dict on this module drops the composed conv_out x quant_conv pack and every pack underneath (inference
+        # tensors carry no version counter, so the key below cannot see an in-place load into them)
+        from ..modules.attention import _invalidate_after_load
+
+        def _drop(module, incompatible_keys):
+            module._pk = None
+            _invalidate_after_load(module, incompatible_keys)
+        self.register_load_state_dict_post_hook(_drop)
 
     def _packed(self):
         co, qc = self.encoder.conv_out, self.quant_conv

@@ -38,7 +38,9 @@ class Packable:
     Replacement is detected through the owning modules' `_parameters` slots: every call checks that each slot still holds the very
     object the pack was built from (a dict lookup per parameter; re-walking `parameters()` would cost ~10 us x 600 packs per step).
     Writes through `p.data` (the reference's LitEma.copy_to, vwm/modules/ema.py) carry their own version counter by PyTorch's design
-    and are invisible here: call `invalidate_packed(model)` after them."""
+    and are invisible here, and so are in-place updates of INFERENCE tensors (parameters created or moved under torch.inference_mode()
+    have no version counter at all): call `invalidate_packed(model)` after either. Every load_state_dict on a root that owns packs
+    (VideoUNet, GeneralConditioner, FrozenOpenCLIPImageEmbedder, AutoencoderKLModeOnly) drops them through a post-hook regardless."""
     _pk = None
     _pk_key = None
     _pk_params = None

@@ -62,8 +62,10 @@ class GeneralConditioner(nn.Module):
             emb.ucg_rate = cfg.get("ucg_rate", 0.0)
             if emb.is_trainable:
                 raise NotImplementedError("is_trainable embedders are a training-time option")
-            if emb.ucg_rate:
-                raise NotImplementedError("ucg_rate > 0 (conditioning dropout) is a training-time option")
+            # ucg_rate / legacy_ucg_value are stored as the reference stores them (encoders/modules.py:85-104): its training YAMLs set
+            # ucg_rate 0.15 and must instantiate here too. The dropout itself is training-time arithmetic on torch's RNG: forward() refuses
+            # it, get_unconditional_conditioning() -- the only entry the sampling path uses -- zeroes the rates around its two passes exactly
+            # like the reference (:172-180).
             for p_ in emb.parameters():
                 p_.requires_grad = False
             emb.eval()
@@ -73,11 +75,12 @@ class GeneralConditioner(nn.Module):
                 emb.input_keys = cfg["input_keys"]
             else:
                 raise KeyError(f"Need either `input_key` or `input_keys` for embedder {type(emb).__name__}")
-            if cfg.get("legacy_ucg_value", None) is not None:
-                raise NotImplementedError("legacy_ucg_value is a training-time option")
-            emb.legacy_ucg_val = None
+            emb.legacy_ucg_val = cfg.get("legacy_ucg_value", None)
             built.append(emb)
         self.embedders = nn.ModuleList(built)
+        # a load_state_dict issued on this container never reaches the children's own hooks: drop every packed weight underneath
+        from ..attention import _invalidate_after_load
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
 
     def _embed(self, emb, batch):
         """One embedder's output list, or None when its key is absent and it adds no sequence entry (modules.py:121-133)."""
@@ -99,6 +102,9 @@ class GeneralConditioner(nn.Module):
         zeroed = set(default(force_zero_embeddings, list()))
         output = {}
         for emb in self.embedders:
+            if emb.ucg_rate and emb.ucg_rate > 0.0:
+                raise NotImplementedError("conditioning dropout (ucg_rate > 0) is applied only in training; sampling goes through "
+                                          "get_unconditional_conditioning(), which disables it like the reference does")
             outs = self._embed(emb, batch)
             if outs is None:
                 continue
@@ -117,8 +123,15 @@ class GeneralConditioner(nn.Module):
         return output
 
     def get_unconditional_conditioning(self, batch_c, batch_uc=None, force_cond_zero_embeddings=None, force_uc_zero_embeddings=None):
-        c = self(batch_c, force_cond_zero_embeddings)
-        uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings)
+        rates = [emb.ucg_rate for emb in self.embedders]
+        for emb in self.embedders:
+            emb.ucg_rate = 0.0
+        try:
+            c = self(batch_c, force_cond_zero_embeddings)
+            uc = self(batch_c if batch_uc is None else batch_uc, force_uc_zero_embeddings)
+        finally:
+            for emb, r in zip(self.embedders, rates):
+                emb.ucg_rate = r
         return c, uc
 
 
@@ -199,6 +212,8 @@ class FrozenOpenCLIPImageEmbedder(AbstractEmbModel, Packable):
         if g["width"] % g["heads"] or g["width"] // g["heads"] not in (64, 80, 128) or g["width"] % 64 or g["mlp"] % 64:
             raise NotImplementedError("vision tower geometry: head dim must be 64 / 80 / 128 and width, MLP multiples of 64")
         self.model = _OpenClipModel(g)  # weights: `conditioner.embedders.0.open_clip.model.visual.*` of vista.safetensors (no download here)
+        from ..attention import _invalidate_after_load
+        self.register_load_state_dict_post_hook(_invalidate_after_load)   # (also when this embedder is loaded on its own)
         self.max_crops, self.pad_to_max_len, self.repeat_to_max_len = 0, False, False
         self.device, self.max_length, self.antialias = device, max_length, antialias
         self.register_buffer("mean", torch.tensor(ops.CLIP_MEAN), persistent=False)

@@ -192,10 +192,39 @@ class _SplitKTLS(threading.local):
 _SPLITK_WS = _SplitKTLS()
 
 
+_GRAPH_WS = {}        # device -> the ONE workspace of every hipGraph warm-up / capture / replay on that device
+_GRAPH_WS_DEPTH = 0   # > 0 inside graph_workspace(): _splitk_workspace hands out _GRAPH_WS instead of a per-stream buffer
+
+
+class graph_workspace:
+    """Context manager for hipGraph warm-up + capture (sampling.FusedLoop): every split-K GEMM enqueued inside uses ONE per-device workspace,
+    allocated here -- OUTSIDE any capture, so it belongs to the ordinary caching allocator and not to a graph's private pool -- instead of a
+    fresh 160 MB buffer per (thread, stream). Graph replays run on the launch stream one after the other, so they may share it; eager work on
+    other streams keeps its per-stream buffers."""
+
+    def __enter__(self):
+        global _GRAPH_WS_DEPTH
+        dev = torch._C._cuda_getDevice()
+        if SPLITK_WS_BYTES and dev not in _GRAPH_WS:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ops.graph_workspace must be entered before the capture starts")
+            _GRAPH_WS[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{dev}")
+        _GRAPH_WS_DEPTH += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _GRAPH_WS_DEPTH
+        _GRAPH_WS_DEPTH -= 1
+        return False
+
+
 def _splitk_workspace(stream):
     """One workspace per (device, stream) of each host thread: launches on one stream are ordered, so they may share it; GEMMs in flight on
     different streams must not (include/vista_hip.h, VkGemmDesc.splitk_ws), and thread ranks (tests) share a stream but enqueue
-    concurrently. Held in thread-local storage, so a worker thread's buffers are released when the thread exits."""
+    concurrently. Held in thread-local storage, so a worker thread's buffers are released when the thread exits. Inside
+    graph_workspace() (hipGraph warm-up / capture) the device's single graph workspace is used instead."""
+    if _GRAPH_WS_DEPTH > 0:
+        return _GRAPH_WS[torch._C._cuda_getDevice()]
     key = (torch._C._cuda_getDevice(), stream.value)
     ws = _SPLITK_WS.ws.get(key)
     if ws is None:

@@ -318,6 +318,16 @@ class FrameShard:
             self.all_reduce_sum(s)
             assert float(s[0]) == self.P * (self.P + 1) / 2, "all_reduce value"
         step(f"all_reduce_sum {B * 64 * 4} B", stats)
+
+        def chunks_agree():
+            # VISTA_A2A_CHUNKS is read per rank from its own environment and decides how many all_to_all_single calls a block issues: ranks
+            # that disagree would issue different collective sequences and hang. Sum and sum of squares pin "all equal" with one all-reduce.
+            v = torch.tensor([float(self.a2a_chunks), float(self.a2a_chunks) ** 2] + [0.0] * (B * 64 - 2), dtype=torch.float32, device=device)
+            self.all_reduce_sum(v)
+            if float(v[0]) != self.P * self.a2a_chunks or float(v[1]) != self.P * self.a2a_chunks ** 2:
+                raise CollectiveError(f"VISTA_A2A_CHUNKS differs between the ranks of a frame-shard group (this rank: {self.a2a_chunks}, "
+                                      f"group mean {float(v[0]) / self.P:.2f}): every rank must issue the same collective sequence")
+        step("VISTA_A2A_CHUNKS agrees across the group", chunks_agree)
         for S, _ in levels:
             def roundtrip(S=S):
                 # value = global (b, t, s) id, so a mis-routed chunk is caught, not just a size mismatch
@@ -330,6 +340,14 @@ class FrameShard:
                 assert torch.equal(self.to_frames(xp, S), x), "to_frames(to_pixels(x)) != x"
                 xb = (x % 251).to(torch.bfloat16)  # the dtype the real step moves
                 assert torch.equal(self.to_frames(self.to_pixels(xb), S), xb), "bf16 round trip"
+                nch = min(self.a2a_chunks, min(self.pixel_counts(S)))
+                if nch > 1:   # the opt-in chunked, asynchronous way back (to_frames_begin / to_frames_end) on the same data
+                    xp2 = self.to_pixels(xb)
+                    out = torch.empty_like(xb)
+                    pend = [self.to_frames_begin(xp2[:, lo:hi].contiguous(), S, nch, ci) for ci, (lo, hi) in enumerate(self.pixel_chunks(S, nch))]
+                    for pnd in pend:
+                        self.to_frames_end(pnd, out)
+                    assert torch.equal(out, xb), "chunked to_frames round trip"
             step(f"frame<->pixel all_to_all_single, S={S} (pixel slices {self.pixel_counts(S)})", roundtrip)
 
             def halo(S=S):
