@@ -182,7 +182,7 @@ int vk_attn_small_bf16(const void* qkv, void* o, int32_t n_img, int32_t heads, i
 
 /* OpenCLIP image preprocessing + patchify (FrozenOpenCLIPImageEmbedder.preprocess, modules.py:304-315, and the im2col of the tower's
  * patch convolution): kornia-0.6.9 antialiased bicubic resize of img f32 [n][3][H][W] in [-1, 1] to out_hw x out_hw (Gaussian blur with
- * (sigma_y, sigma_x) / odd kernel sizes (ks_y, ks_x) <= 15, reflect border, then bicubic align_corners=True), (x + 1) / 2, CLIP mean / std
+ * (sigma_y, sigma_x) / odd kernel sizes (ks_y, ks_x) <= 63, reflect border, then bicubic align_corners=True), (x + 1) / 2, CLIP mean / std
  * (HOST arrays of 3 floats), written as the bf16 A operand of the patch-embedding GEMM:
  *   out[(img * (1 + g*g) + 1 + py*g + px) * ldo + c*patch*patch + ky*patch + kx],  g = out_hw / patch.
  * Only those columns are written: the caller zero-fills `out` (class-token row of every image, K padding) once. */

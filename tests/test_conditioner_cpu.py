@@ -153,6 +153,29 @@ def test_clip_oracle_is_pinned_to_hf_and_regenerates_the_golden():
     assert torch.allclose(CO.restated_visual(sd, TINY, pix), out, atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("f", [2, 3])
+def test_clip_oracle_resize_agrees_with_an_independent_float64_implementation(f):
+    """The kornia-0.6.9 antialias resize is restated in oracle/clip_oracle.py (kornia is not installed: "parity unpinned" against kornia
+    itself). What CAN be pinned: the restatement against an implementation that shares no code with it -- scipy's separable Gaussian
+    (mode='mirror' = torch 'reflect', radius = kornia's kernel size // 2) + torch's float64 bicubic (a = -0.75, align_corners=True)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from scipy.ndimage import gaussian_filter1d
+    from oracle import clip_oracle as CO
+    from vista_amd import ops
+    H = W = 224 * f
+    g = torch.Generator().manual_seed(f)
+    img = torch.tanh(torch.randn(1, 3, H, W, generator=g) * 1.5)
+    sigma, ks = ops.antialias_blur_params(H, 224)
+    a = img.double().numpy()
+    a = gaussian_filter1d(a, sigma, axis=2, mode="mirror", radius=ks // 2)
+    a = gaussian_filter1d(a, sigma, axis=3, mode="mirror", radius=ks // 2)
+    want = F.interpolate(torch.from_numpy(np.ascontiguousarray(a)), size=(224, 224), mode="bicubic", align_corners=True)
+    want = torch.stack([((want[0, c] + 1) / 2 - ops.CLIP_MEAN[c]) / ops.CLIP_STD[c] for c in range(3)])
+    got = CO.preprocess(img, 224)[0].double()
+    assert (got - want).abs().max().item() <= 1e-3
+
+
 def test_antialias_blur_parameters_follow_kornia_0_6_9():
     from vista_amd import ops
     # 576x1024 -> 224: vertical factor 2.571 -> sigma 0.7857, ks int(max(3.14, 3)) = 3; horizontal 4.571 -> sigma 1.7857, ks int(7.14) = 7

@@ -47,6 +47,61 @@ def test_clip_preprocess_patchify_vs_restated_kornia(H, W):
     assert err <= 1.2e-2
 
 
+def _unpatch(got, n):
+    """(n*257, 640) patch rows -> (n, 3, 224, 224) image (the inverse of the kernel's im2col)."""
+    g = got.view(n, 257, 640)[:, 1:, :588].reshape(n, 16, 16, 3, 14, 14)
+    return g.permute(0, 3, 1, 4, 2, 5).reshape(n, 3, 224, 224)
+
+
+def _norm(v, c):
+    from vista_amd import ops
+    return ((v + 1.0) / 2.0 - ops.CLIP_MEAN[c]) / ops.CLIP_STD[c]
+
+
+@pytest.mark.parametrize("H,W", [(448, 448), (576, 1024), (2240, 4096)])   # the last: blur kernel 35 x 63 (the old 15-tap cap refused it)
+def test_clip_preprocess_properties_constant_and_ramp(H, W):
+    """Properties no restatement is needed for (the kornia-0.6.9 resize is otherwise pinned only to oracle/clip_oracle.py):
+    a normalised Gaussian and a bicubic with align_corners=True both reproduce constants exactly and linear ramps exactly away from the
+    reflect-padded border, so resize(constant) = constant and resize(ramp)(i) = ramp(i (W-1)/223)."""
+    from vista_amd import ops
+    const = torch.full((1, 3, H, W), 0.37)
+    got = _unpatch(ops.clip_preprocess_patches(const.cuda()).float().cpu(), 1)
+    for c in range(3):
+        assert (got[0, c] - _norm(0.37, c)).abs().max().item() <= 8e-3     # one bf16 step at |value| ~ 1.5
+    ramp = torch.linspace(-0.9, 0.9, W).view(1, 1, 1, W).expand(1, 3, H, W).contiguous()
+    got = _unpatch(ops.clip_preprocess_patches(ramp.cuda()).float().cpu(), 1)
+    xs = torch.arange(224, dtype=torch.float64) * (W - 1) / 223.0
+    want = -0.9 + 1.8 * xs / (W - 1)
+    _, ks = ops.antialias_blur_params(W, 224)
+    margin = int(ks / 2 * 224 / W) + 3                                      # output columns whose blur window touches the reflected border
+    for c in range(3):
+        e = (got[0, c, :, margin:224 - margin] - _norm(want[margin:224 - margin], c).float()).abs().max().item()
+        assert e <= 1.2e-2, (c, e)
+
+
+@pytest.mark.parametrize("f", [2, 4])
+def test_clip_preprocess_integer_downscale_vs_independent_float64(f):
+    """Integer-factor downscale against an implementation that shares no code with this package or its oracle: scipy's separable Gaussian
+    (mode='mirror' = torch's 'reflect', truncated to kornia 0.6.9's kernel size int(max(4 sigma, 3)) made odd, sigma = (f - 1) / 2) followed by
+    torch's own float64 bicubic (a = -0.75, align_corners=True, clamped taps)."""
+    import numpy as np
+    from scipy.ndimage import gaussian_filter1d
+    from vista_amd import ops
+    H = W = 224 * f
+    img = torch.tanh(_rnd(1, 3, H, W, seed=11) * 1.5)
+    sigma, ks = ops.antialias_blur_params(H, 224)
+    assert ks % 2 == 1 and ks == (int(max(4 * sigma, 3)) | 1) and abs(sigma - (f - 1) / 2) < 1e-12
+    a = img.double().numpy()
+    a = gaussian_filter1d(a, sigma, axis=2, mode="mirror", radius=ks // 2)
+    a = gaussian_filter1d(a, sigma, axis=3, mode="mirror", radius=ks // 2)
+    want = F.interpolate(torch.from_numpy(np.ascontiguousarray(a)), size=(224, 224), mode="bicubic", align_corners=True)
+    got = _unpatch(ops.clip_preprocess_patches(img.cuda()).float().cpu(), 1)
+    for c in range(3):
+        e = (got[0, c] - _norm(want[0, c], c).float()).abs().max().item()
+        print(f"[parity] clip preprocess x{f} downscale vs scipy + torch float64, channel {c}: max |err| {e:.3e}")
+        assert e <= 1.2e-2
+
+
 @pytest.mark.parametrize("n,heads,S,D", [(2, 4, 257, 80), (1, 16, 257, 80), (3, 2, 50, 64), (1, 2, 300, 128), (2, 1, 5, 80)])
 def test_attn_small_vs_sdpa(n, heads, S, D):
     from vista_amd import ops

@@ -237,6 +237,7 @@ __global__ void ens_var_final_kernel(const double* __restrict__ partial, double*
 
 
 // ---------------------------------------------------------------------------------------------------------------
+constexpr int CLIP_MAX_KS = 63;  // largest odd Gaussian kernel of the antialias blur (a side of ~7000 px resized to 224)
 // OpenCLIP image preprocessing + patchify in one pass (FrozenOpenCLIPImageEmbedder.preprocess, vwm/modules/encoders/modules.py:304-315,
 // then the 14x14 / stride-14 patch convolution's im2col): kornia 0.6.9 `resize(x, (224, 224), "bicubic", align_corners=True, antialias=True)`
 // = separable Gaussian blur (reflect border; sigma = (factor - 1) / 2 per axis, kernel size int(max(4 sigma, 3)) made odd -- only when
@@ -253,6 +254,15 @@ __global__ __launch_bounds__(EW_THREADS) void clip_preprocess_kernel(const float
                                                                      float m0, float m1, float m2, float s0, float s1, float s2) {
     const int gp = out_hw / ps;
     const long long total = (long long)n_img * 3 * out_hw * out_hw;
+    // Gaussian taps (the same for every output value): once per workgroup, in LDS, in the order and arithmetic of the per-thread form they
+    // replace (a runtime-indexed register array lives in scratch: 2 x 63 floats per lane); ks == 1 = no blur along that axis
+    __shared__ float gy[CLIP_MAX_KS], gx[CLIP_MAX_KS];
+    if ((int)threadIdx.x < ks_y) { const float d = (float)((int)threadIdx.x - ks_y / 2); gy[threadIdx.x] = ks_y > 1 ? expf(-d * d / (2.f * sig_y * sig_y)) : 1.f; }
+    if ((int)threadIdx.x < ks_x) { const float d = (float)((int)threadIdx.x - ks_x / 2); gx[threadIdx.x] = ks_x > 1 ? expf(-d * d / (2.f * sig_x * sig_x)) : 1.f; }
+    __syncthreads();
+    float ny = 0.f, nx = 0.f;
+    for (int k = 0; k < ks_y; ++k) ny += gy[k];
+    for (int k = 0; k < ks_x; ++k) nx += gx[k];
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int ox = (int)(i % out_hw);
         const int oy = (int)((i / out_hw) % out_hw);
@@ -266,10 +276,6 @@ __global__ __launch_bounds__(EW_THREADS) void clip_preprocess_kernel(const float
         const float A = -0.75f;
         const float wy[4] = {cubic2(ty + 1.f, A), cubic1(ty, A), cubic1(1.f - ty, A), cubic2(2.f - ty, A)};
         const float wx[4] = {cubic2(tx + 1.f, A), cubic1(tx, A), cubic1(1.f - tx, A), cubic2(2.f - tx, A)};
-        // Gaussian taps (normalised); ks == 1 means no blur (no downscaling along that axis)
-        float gy[15], gx[15], ny = 0.f, nx = 0.f;
-        for (int k = 0; k < ks_y; ++k) { const float d = (float)(k - ks_y / 2); gy[k] = ks_y > 1 ? expf(-d * d / (2.f * sig_y * sig_y)) : 1.f; ny += gy[k]; }
-        for (int k = 0; k < ks_x; ++k) { const float d = (float)(k - ks_x / 2); gx[k] = ks_x > 1 ? expf(-d * d / (2.f * sig_x * sig_x)) : 1.f; nx += gx[k]; }
         float acc = 0.f;
         for (int a = 0; a < 4; ++a) {
             int yy = iy - 1 + a;
@@ -388,7 +394,7 @@ extern "C" int vk_clip_preprocess_patches(const float* img, void* out, int32_t n
                                           int32_t ldo, float sigma_y, float sigma_x, int32_t ks_y, int32_t ks_x, const float* mean3,
                                           const float* std3, void* stream) {
     if (!img || !out || !mean3 || !std3 || n_img <= 0 || H < 2 || W < 2 || out_hw <= 0 || patch <= 0 || (out_hw % patch) != 0 ||
-        ldo < 3 * patch * patch || ks_y < 1 || ks_x < 1 || ks_y > 15 || ks_x > 15 || !(ks_y & 1) || !(ks_x & 1) || !(sigma_y > 0.f) || !(sigma_x > 0.f))
+        ldo < 3 * patch * patch || ks_y < 1 || ks_x < 1 || ks_y > CLIP_MAX_KS || ks_x > CLIP_MAX_KS || !(ks_y & 1) || !(ks_x & 1) || !(sigma_y > 0.f) || !(sigma_x > 0.f))
         return VK_EINVAL;
     // the caller zero-fills `out` once (class-token rows and the K padding); this launch writes the 3*patch*patch image columns
     EW_LAUNCH(clip_preprocess_kernel, (long long)n_img * 3 * out_hw * out_hw, img, (uint16_t*)out, n_img, H, W, out_hw, patch, ldo, sigma_y, sigma_x,
