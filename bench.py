@@ -158,11 +158,20 @@ def gemm_rooflines(ops, n_img, H, W):
     pw_geglu = ops.pack_geglu(rn(8 * C, C) * C ** -0.5, rn(8 * C))
     pw_conv = ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C))
     x3 = x.view(n_img, H * W, C)
+    pw_ffo = ops.pack_ff_out(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C))
+    pw_ffo_plain = ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C))
     cases = [
-        ("gemm_kernel[dense,linear,256x320] level-0 projection 460800x320x320 (+residual)", lambda: ops.linear(x, pw_lin, res1=res),
+        # (since round 4 the launcher sends this shape to gemm_stream.hip: weights in registers, activations through an LDS-DMA ring)
+        ("gemm_stream_kernel / gemm_kernel[dense,linear] level-0 projection 460800x320x320 (+residual)", lambda: ops.linear(x, pw_lin, res1=res),
          2.0 * M * C * C, 3.0 * M * C * 2, "hbm"),
+        # (level-0 GEGLU as its own launch: no longer on the step's path since round 4 -- the level-0 FeedForward is ff_fused_kernel, next entry --
+        #  kept as the figure VERDICT r3 tracks; levels 1 / 2 still run this kernel)
         ("gemm_kernel[dense,geglu,256x256] level-0 GEGLU 460800x320->2560 (gated to 1280)", lambda: ops.linear(x, pw_geglu),
          2.0 * M * 8 * C * C, M * C * 2 + M * 4 * C * 2, "mfma"),
+        ("ff_fused_kernel level-0 FeedForward 460800x320->1280(GEGLU)->320 (+residual), hidden activation never written", lambda: ops.ff_fused(x, pw_geglu, pw_ffo, res1=res),
+         2.0 * M * 8 * C * C + 2.0 * M * 4 * C * C, 3.0 * M * C * 2, "mfma"),
+        ("the same FeedForward as two launches (GEGLU GEMM + out-projection GEMM: the round-3 path)", lambda: ops.linear(ops.linear(x, pw_geglu), pw_ffo_plain, res1=res),
+         2.0 * M * 8 * C * C + 2.0 * M * 4 * C * C, 3.0 * M * C * 2 + 2.0 * M * 4 * C * 2, "mfma"),
         ("gemm_kernel[conv3x3,linear,256x320] level-0 conv 320->320 @72x128", lambda: ops.conv3x3(x3, pw_conv, n_img, H, W),
          2.0 * M * C * 9 * C, 2.0 * M * C * 2, "mfma"),
     ]

@@ -1,5 +1,5 @@
 """Run ONE hot kernel at a BASELINE shape a few times (for rocprofv3 --pmc passes).
-usage: python tools/one_kernel.py {attn|conv|geglu|ffout|linear} [level 0|1|2]"""
+usage: python tools/one_kernel.py {attn|conv|geglu|ffout|linear|ffused} [level 0|1|2]"""
 import os
 import sys
 
@@ -34,7 +34,11 @@ elif kind == "ffout":
     h = torch.randn(M, 4 * C, device="cuda").to(BF16)
     po = ops.pack_linear(torch.randn(C, 4 * C) * (4 * C) ** -0.5, torch.randn(C))
     fn = lambda: ops.linear(h, po, res1=x)  # noqa: E731
-else:  # K = C projection with a residual (attention out / proj_out): the 128x160 two-per-CU tile at levels 0 / 1
+elif kind == "ffused":  # level-0 FeedForward as ONE kernel (round 4): GEGLU in-projection -> gelu -> out-projection, + residual
+    pg = ops.pack_geglu(torch.randn(8 * C, C) * C ** -0.5, torch.randn(8 * C))
+    po = ops.pack_ff_out(torch.randn(C, 4 * C) * (4 * C) ** -0.5, torch.randn(C))
+    fn = lambda: ops.ff_fused(x, pg, po, res1=x)  # noqa: E731
+else:  # K = C projection with a residual (attention out / proj_out): gemm_stream.hip at level 0 since round 4, 128x160 two-per-CU tiles at level 1
     pw = ops.pack_linear(torch.randn(C, C) * C ** -0.5, torch.randn(C))
     res = torch.randn(M, C, device="cuda").to(BF16)
     fn = lambda: ops.linear(x, pw, res1=res)  # noqa: E731
