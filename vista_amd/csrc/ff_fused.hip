@@ -102,8 +102,12 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
     // one of a DMA wave's 15 pieces of a step: q = 0..9: W1 chunk jw1 -> W1 slot `sl` (slab q >> 1, row block tgw + 4 (q & 1));
     // q = 10..14: W2 chunk jw2 -> W2 slot `sl` (piece tgw + 4 (q - 10)). Address = uniform base (SGPR pair: tensor + chunk + piece) + ONE
     // 32-bit per-lane byte offset per tensor: fifteen 64-bit per-lane pointers would not fit beside the 160 accumulator registers.
-    const uint32_t w1voff = (uint32_t)w1off * 2u, w2voff = (uint32_t)w2off * 2u;
+    const uint32_t w1voff_ = (uint32_t)w1off * 2u, w2voff_ = (uint32_t)w2off * 2u;
     auto dma_piece = [&](const int q, const int sl, const int jw1, const int jw2) {
+        // (the offsets pass through an empty asm at every use: otherwise the compiler hoists all fifteen 64-bit per-lane addresses out of the
+        //  chunk loop -- 30 registers the 160-register accumulator leaves no room for; they were spilled and reloaded around every tile)
+        uint32_t w1voff = w1voff_, w2voff = w2voff_;
+        asm volatile("" : "+v"(w1voff), "+v"(w2voff));
         if (q < 10) {
             const char* ub = (const char*)W1g + (size_t)jw1 * (2 * FF_HC * FF_C * 2) + (64 * (q >> 1) + (q & 1) * 32 * FF_C) * 2;
             __builtin_amdgcn_global_load_lds((gptr_t)(ub + w1voff), (lptr_t)(smem + OFF_W1 + sl * W1_SLOT + tgw * 1024 + (q >> 1) * 8192 + (q & 1) * 4096), 16, 0, 0);
@@ -120,16 +124,9 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m0 = tile * FF_BM;
         // ---------------- prologue: W1(0) -> slot 0 (DMA waves), x fragments (in-projection waves), row statistics (everyone) ----------------
-        bf16x8_t xf[20];   // B operand of the in-projection: lane (l31, lh) holds k = 16 ks + 8 lh .. + 7 of token l31 (in-projection waves only)
         if (!role_in) {
 #pragma unroll
             for (int q = 0; q < 10; ++q) dma_piece(q, 0, 0, 0);
-        } else {
-            int m = m0 + 32 * tgw + l31;
-            if (m >= p1.M) m = p1.M - 1;
-            const uint16_t* xr = Xg + (size_t)m * p1.lda + 8 * lh;
-#pragma unroll
-            for (int ks = 0; ks < 20; ++ks) xf[ks] = *(const bf16x8_t*)(xr + 16 * ks);
         }
         if (p1.ln_stats != nullptr) {
             for (int r = tid; r < FF_BM; r += FF_NT) {
@@ -147,6 +144,18 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
             // =============================== in-projection waves ===============================
             float rs = 1.f, nrm = 0.f;
             if (p1.ln_stats != nullptr) { const float2 t = lnrow[32 * tgw + l31]; rs = t.y; nrm = -t.x * t.y; }
+            // x fragments of this wave's 32 tokens: B operand of the in-projection, lane (l31, lh) holds k = 16 ks + 8 lh .. + 7 of token l31.
+            // Loaded HERE, not next to the prologue's DMA: issued before the prologue barrier they were live across its bookkeeping, and the
+            // allocator (one register budget for both roles) spilled 12 of the 20 fragments to scratch and reloaded them -- 300 bytes per lane
+            // and tile = 560 MB of scratch writes per launch (rocprofv3 WRITE_SIZE 657 MB for 295 MB of output).
+            bf16x8_t xf[20];
+            {
+                int m = m0 + 32 * tgw + l31;
+                if (m >= p1.M) m = p1.M - 1;
+                const uint16_t* xr = Xg + (size_t)m * p1.lda + 8 * lh;
+#pragma unroll
+                for (int ks = 0; ks < 20; ++ks) xf[ks] = *(const bf16x8_t*)(xr + 16 * ks);
+            }
             // Step j (W1(j) in W1 slot j & 1): (1) the 40 in-projection MFMAs, bare, the two fragments' accumulator chains alternating (a VALU
             // instruction between two MFMAs of ONE chain costs the chain its back-to-back forwarding: +43 cycles per MFMA, measured as 1750
             // cycles for 20 woven MFMAs against 920 bare); (2) the GEGLU of all 16 gates of the lane in one unfenced block (eight independent
