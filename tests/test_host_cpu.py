@@ -443,16 +443,17 @@ def test_gemm_launch_rules_are_pinned():
     # one GPU, 50 images
     assert choice(full, 320, 320, stats=True) == (5, 1)         # K = N projections: 128x160, two workgroups per CU
     assert choice(L1, 640, 640, stats=True) == (5, 1)
-    assert choice(L2, 1280, 1280, stats=True) == (4, 1)         # K = N = 1280: back on the big tile
-    assert choice(full, 960, 320) == (4, 1)                     # q|k|v: N = 3K
-    assert choice(full, 320, 1280, stats=True) == (4, 1)        # FeedForward out: K = 4N
+    assert choice(L2, 1280, 1280, stats=True) == (7, 1)         # K = N = 1280: back on the big tile (7 = its eight-wave pipelined kernel, round 4)
+    assert choice(full, 960, 320) == (7, 1)                     # q|k|v: N = 3K
+    assert choice(full, 320, 1280, stats=True) == (7, 1)        # FeedForward out: K = 4N
     assert choice(full, 2560, 320, epi=ops.EPI_GEGLU) == (3, 1)
-    assert choice(L1, 5120, 640, epi=ops.EPI_GEGLU) == (4, 1)   # 256x320 since the LDS-staged epilogue (K >= 640)
+    assert choice(L1, 5120, 640, epi=ops.EPI_GEGLU) == (4, 1)   # 256x320 since the LDS-staged epilogue (K >= 640); sixteen waves (the pipelined kernel has no GEGLU epilogue)
     assert choice(L2, 10240, 1280, epi=ops.EPI_GEGLU) == (3, 1)
-    assert choice(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128) == (4, 1)
+    assert choice(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128) == (7, 1)
+    assert choice(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, tile_cfg=4) == (4, 1)   # forced: the sixteen-wave kernel
     # one rank of 8 (7 images)
     r0, r1, r2 = 7 * 9216, 7 * 2304, 7 * 576
-    assert choice(r0, 320, 1280, stats=True) == (4, 1)          # 252 tiles: one full round
+    assert choice(r0, 320, 1280, stats=True) == (7, 1)          # 252 tiles: one full round
     assert choice(r1, 640, 640, stats=True) == (5, 1)           # 126 tiles of 256x320 would fill half the chip
     assert choice(r1, 640, 2560, stats=True) == (5, 1)
     assert choice(r2, 1280, 5120, stats=True) == (5, 1)

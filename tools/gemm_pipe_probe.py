@@ -1,0 +1,68 @@
+"""Pipelined eight-wave 256x320 GEMM variant (ops.TILE_CFG = 7, vista_amd/csrc/gemm_pipe.hip) against the sixteen-wave 256x320 kernel (TILE_CFG = 4):
+bitwise comparison on the BASELINE shapes and on ragged ones, then timing.   usage: python tools/gemm_pipe_probe.py [images]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vista_amd import ops  # noqa: E402
+from tools.gemm_sweep2 import Norm, timeit  # noqa: E402
+
+BF16 = torch.bfloat16
+
+
+def flat(r):
+    return [t for t in (r if isinstance(r, (tuple, list)) else (r,)) if torch.is_tensor(t)]
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    rn = lambda *s: torch.randn(*s, device="cuda")  # noqa: E731
+    bad = 0
+    for C, H, W, n in ((320, 72, 128, N), (640, 36, 64, N), (1280, 18, 32, N), (320, 20, 24, 3), (640, 9, 13, 5)):
+        T = 25 if n % 25 == 0 else n
+        M = n * H * W
+        x = rn(M, C).to(BF16)
+        res = rn(M, C).to(BF16)
+        h4 = rn(M, 4 * C).to(BF16)
+        st = ops.rowstats(x)
+        nrm = Norm(C)
+        x3 = x.view(n, H * W, C)
+        rv = rn(n, C)
+        cases = {
+            "linear+res+stats": (lambda pw=ops.pack_linear(rn(C, C) * C ** -0.5, rn(C)): ops.linear(x, pw, res1=res, emit_stats=True), 2.0 * M * C * C),
+            "qkv_lnfold": (lambda pw=ops.pack_linear_cat([rn(C, C) * C ** -0.5 for _ in range(3)], ln=nrm): ops.linear(x, pw, ln=st), 2.0 * M * 3 * C * C),
+            "ff_out+res+stats": (lambda pw=ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C)): ops.linear(h4, pw, res1=res, emit_stats=True), 2.0 * M * 4 * C * C),
+            "ff_out+blend": (lambda pw=ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C)): ops.linear(
+                h4, pw, res1=res, alpha=0.4, res2=x, rowvec2=rv, beta=0.6, rows_per_vec=H * W), 2.0 * M * 4 * C * C),
+            "conv3x3": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, n, H, W), 2.0 * M * 9 * C * C),
+            "conv3x3+emb+res": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, n, H, W, rowvec=rv, res1=x3), 2.0 * M * 9 * C * C),
+            "conv_t3": (lambda pw=ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C)): ops.conv_t3(x3, pw, T, H * W), 2.0 * M * 3 * C * C),
+        }
+        if H % 2 == 0 and W % 2 == 0:
+            cases["conv3x3_s2"] = (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, n, H, W, stride=2), 2.0 * M / 4 * 9 * C * C)
+        for name, (fn, flop) in cases.items():
+            out = {}
+            for cfg in (4, 7):
+                ops.TILE_CFG = cfg
+                out[cfg] = [t.clone() for t in flat(fn())]
+            same = all(torch.equal(a, b) for a, b in zip(out[4], out[7]))
+            bad += not same
+            ms = {}
+            for _ in range(3):
+                for cfg in (4, 7):
+                    ops.TILE_CFG = cfg
+                    ms[cfg] = min(ms.get(cfg, 1e9), timeit(fn))
+            ops.TILE_CFG = 0
+            err = max((a.float() - b.float()).abs().max().item() for a, b in zip(out[4], out[7]))
+            print(f"C {C:5d} M {M:7d} {name:18s} bitwise {'OK ' if same else 'DIFF'} max|d| {err:.3g}   cfg4 {ms[4]:.4f} ms  cfg7 {ms[7]:.4f} ms  "
+                  f"{100 * (ms[4] / ms[7] - 1):+.1f} %   {flop / ms[7] / 1e9:.0f} TFLOP/s", flush=True)
+        del x, res, h4, cases
+        torch.cuda.empty_cache()
+    print("MISMATCHES", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -12,7 +12,7 @@ LIB = os.path.join(LIBDIR, "libvista_hip.so")
 # per-file flags. ff_fused.hip: the SLP vectorizer packs the GEGLU arithmetic into v_pk_fma_f32 / v_pk_mul_f32 and pays for the operand
 # pairing with a v_mov per packed instruction -- a third more VALU instructions in a kernel whose in-projection waves are VALU-issue bound
 EXTRA_FLAGS = {"ff_fused.hip": ["-fno-slp-vectorize"]}
-SOURCES = ["gemm.hip", "gemm_stream.hip", "gemm_fp8.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "gemm_pipe.hip", "gemm_stream.hip", "gemm_fp8.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 
 
 def hipcc():

@@ -35,6 +35,10 @@
 
 #include "gemm_common.h"
 
+// gemm_pipe.hip: the eight-wave pipelined 256x320 variant (tile_cfg 7); fit = 1 when it takes the problem
+extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d);
+extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream);
+
 namespace {
 
 // 128x160 two-per-CU tiles for DENSE LINEAR GEMMs with N <= K <= this. Same-box sweep (profiles/r03_tile5_sweep.txt): K = N = 320 projections
@@ -429,7 +433,7 @@ int launch_cfg(const VkGemmDesc* d, hipStream_t stream, int ksplit = 1) {
 // rounding N up to 256 wastes > 10% of the MFMA work), 256x128, 128x128 -- but a variant is only taken if its grid covers the
 // chip (>= 192 workgroups, i.e. at least 3/4 of the CUs with one workgroup each; the 128x128 variant runs two per CU). Small-M problems (deep UNet levels, and every
 // level of a frame-sharded multi-GPU run) therefore fall back to smaller tiles instead of leaving CUs idle.
-struct TileChoice { int cfg, ksplit; };  // cfg: 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320, 5 = 128x160 (two workgroups per CU)
+struct TileChoice { int cfg, ksplit; };  // cfg: 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320, 5 = 128x160 (two workgroups per CU), 7 = 256x320 pipelined (eight waves)
 
 // cfg 5 exists for DENSE / LINEAR / bf16-out GEMMs only (the HBM-bound K = C projections it is meant for): everything else maps it to 4
 inline bool cfg5_ok(const VkGemmDesc* d) { return d->amode == AMODE_DENSE && d->epi == EPI_LINEAR && !d->out_f32 && (d->N % 160) == 0; }
@@ -440,6 +444,7 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     int cfg = force;
     if (d->mx8_out) cfg = 4;  // MX-fp8 output lives in the LDS-staged epilogue of whole 320-column tiles (validate() checked N and mx8_cols)
     if (cfg == 5 && !cfg5_ok(d)) cfg = 4;
+    if (cfg == 7 && !vk_gemm_pipe_fit(d)) cfg = 4;
     if (cfg == 4 && amode == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
     if (cfg == 0) {
         auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
@@ -499,13 +504,17 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
             cfg = ok320s ? 4 : 3;
         }
     }
+    // 256x320 chosen by the rules above (not forced): the eight-wave pipelined kernel where it takes the problem (gemm_pipe.hip; same-box
+    // sweep +14-17 % on the 3x3 convs, +5-15 % on the dense / temporal shapes, bitwise the same results). VISTA_GEMM_PIPE=0: A/B hook.
+    static const bool pipe_on = [] { const char* e = getenv("VISTA_GEMM_PIPE"); return !e || atoi(e) != 0; }();
+    if (cfg == 4 && ksplit == 1 && force == 0 && pipe_on && vk_gemm_pipe_fit(d)) cfg = 7;
     return {cfg, ksplit};
 }
 
 // (block-tile width, wave columns) of a variant: the row-sum slabs of rowstat_out are one per (column tile, wave column)
 inline void tile_geometry(int cfg, int& bn, int& wn) {
     if (cfg == 5) { bn = 160; wn = 1; }
-    else if (cfg == 4) { bn = 320; wn = 2; }
+    else if (cfg == 4 || cfg == 7) { bn = 320; wn = 2; }
     else if (cfg == 3) { bn = 256; wn = 4; }
     else if (cfg == 2) { bn = 128; wn = 4; }
     else { bn = 128; wn = 2; }
@@ -520,6 +529,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
     if constexpr (AMODE != AMODE_CONV3D) {
         // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
         // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
+        if (t.cfg == 7) return vk_gemm_pipe_launch(d, stream);   // eight 64x160 wave tiles, pipelined K-step (gemm_pipe.hip)
         if (t.cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream, t.ksplit);
     }
     // 256x256 runs as SIXTEEN waves (4 per SIMD, 64x64 wave tiles, <= 128 VGPRs): same bytes per FLOP as the 8-wave layout, but twice
@@ -531,7 +541,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 
 inline int validate(const VkGemmDesc* d) {
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & 7) > 6 || d->tile_cfg > 7) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || d->tile_cfg > 7) return VK_EINVAL;
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;

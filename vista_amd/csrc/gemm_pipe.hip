@@ -1,0 +1,297 @@
+// Eight-wave pipelined 256x320 variant of the tiled bf16 GEMM (tile_cfg 7): DENSE / CONV3X3 / TEMPORAL3 loaders x LINEAR epilogue, bf16 out.
+// Same math, LDS image, fragment layout and epilogues (gemm_common.h) as gemm.hip's sixteen-wave 256x320 kernel -- results are bitwise the
+// same -- but the K-step is written for the matrix pipe instead of for occupancy:
+//   * eight waves, wave tile 64 x 160 (2 activation x 5 weight fragments, 160 accumulator registers, 256-VGPR budget, two waves per SIMD):
+//     7 ds_read_b128 per 10 MFMAs instead of 6 per 5;
+//   * fragments double-buffered ACROSS the K-step barrier: the last k-substep's ten MFMAs are issued after the barrier and cover the first
+//     fragment reads of the next stage, so no LDS latency is exposed anywhere in the loop (the sixteen-wave kernel waits on lgkmcnt(0) before
+//     almost every MFMA pair and relies on its four waves per SIMD to fill the holes);
+//   * the nine LDS-DMA pieces of the next tile are issued BETWEEN the MFMAs of the first two k-substeps, one per MFMA pair. An LDS-DMA issue
+//     stalls its wave for ~120 cycles (profiles/r04_ff_fused_notes.txt); at the head of the K-step, where the other variants issue them, both
+//     waves of a SIMD stall together and the pipe idles, here the partner wave's MFMAs run in the gap;
+//   * the pieces are BUFFER loads (buffer_load_dwordx4 ... lds): a wave-uniform resource per operand in SGPRs, ONE 32-bit per-lane offset for
+//     the weights and one per activation row group, everything that changes per piece / K-step / tap in scalar registers. Out-of-image conv
+//     taps, frames outside the window and rows past M are out-of-range offsets, which the hardware returns as zeros: no clamping, no zero
+//     word, no 64-bit per-lane pointers (the sixteen-wave kernel keeps nine of them live across the loop).
+// Internal entry points, called by gemm.hip's launcher.
+#include <stdlib.h>
+
+#include "common.h"
+#include "vista_hip.h"
+
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int PBM = 256, PBN = 320, PNT = 512;
+constexpr int PRPP = 64;                       // tile rows per piece (8 waves x 8 rows)
+constexpr int PAP = PBM / PRPP, PWP = PBN / PRPP;
+constexpr int PA_BYTES = PBM * 128, PSTAGE = (PBM + PBN) * 128;
+constexpr int PFX = 5, PFY = 2;                // weight (MFMA row operand) / activation (column operand) fragments per wave
+constexpr unsigned P_OOB = 0xffffff00u;        // an offset no resource below reaches (host: every operand < P_LIMIT bytes)
+constexpr unsigned long long P_LIMIT = 0xfffff000ull;
+static_assert(PAP == 4 && PWP == 5, "the piece schedule is written for 5 weight + 4 activation pieces");
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
+
+template <int AMODE, bool NT_A>
+__global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
+    constexpr int LN_OFF = 2 * PSTAGE, EV_OFF = LN_OFF + PBM * 8;
+    constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
+    __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE + PBM * 8 + epi_vec_floats(PBN) * 4];
+
+    const int tilesN = p.N / PBN;
+    const int tilesM = (p.M + PBM - 1) / PBM;
+    const int ntiles = tilesM * tilesN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int logical = xcd_remap(blockIdx.x, ntiles);
+    int tn, tm;   // tile order: as gemm.hip (column tile fastest unless the weights overflow the L2)
+    if (tilesN < 8 || (long long)p.N * p.K * 2 <= (3LL << 20)) {
+        tn = logical % tilesN;
+        tm = logical / tilesN;
+    } else {
+        constexpr int GM = 8;
+        const int panel = logical / (GM * tilesN), r = logical - panel * (GM * tilesN);
+        const int gm = (tilesM - panel * GM < GM) ? tilesM - panel * GM : GM;
+        tm = panel * GM + r % gm;
+        tn = r / gm;
+    }
+    const int m0 = tm * PBM, n0 = tn * PBN;
+
+    // ---- staging assignment: 16-byte chunk lc of tile rows lr + 64 * i; the XOR swizzle lives in the SOURCE chunk index (gemm.hip) ----
+    const int lc = tid & 7, lr = tid >> 3;
+    const int lsrc = lc ^ ((lr >> 1) & 7);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // weights: rows n0 .. n0 + 319 of W[N][K]
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.Wt + (size_t)n0 * p.K), 0, (int)((unsigned)PBN * (unsigned)p.K * 2u), 0x00020000);
+    const unsigned voff_w = ((unsigned)lr * (unsigned)p.K + (unsigned)lsrc * 8u) * 2u;
+    const unsigned wpass = (unsigned)PRPP * (unsigned)p.K * 2u;   // bytes between the row groups of two weight pieces
+
+    // activations: a resource, per-lane offsets of the row groups, validity bits
+    __amdgpu_buffer_rsrc_t ra;
+    unsigned voff_a[PAP];   // DENSE / TEMPORAL3: [0] only (the row groups are a uniform stride `apass` apart)
+    unsigned amask = 0;     // CONV3X3: per piece 3 row-valid + 3 column-valid bits (tap (ky, kx) valid = row bit ky & column bit kx); TEMPORAL3: 3 frame bits
+    unsigned apass = 0;
+    if (AMODE == AMODE_DENSE) {
+        const int rows = (p.M - m0 < PBM) ? p.M - m0 : PBM;
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.A + (size_t)m0 * p.lda), 0,
+                                               (int)(((unsigned)(rows - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u), 0x00020000);
+        voff_a[0] = ((unsigned)lr * (unsigned)p.lda + (unsigned)lsrc * 8u) * 2u;
+        apass = (unsigned)PRPP * (unsigned)p.lda * 2u;
+    } else if (AMODE == AMODE_CONV3X3) {
+        const int hw = p.Hout * p.Wout;
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)(p.M / hw) * (unsigned)(p.H * p.Wd) * (unsigned)p.Cin * 2u), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < PAP; ++i) {
+            const int m = m0 + lr + PRPP * i;
+            const int img = m / hw;
+            const int rem = m - img * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            const int y0 = oy * p.stride - (p.asym_pad ? 0 : 1), x0 = ox * p.stride - (p.asym_pad ? 0 : 1);
+            // tap (0, 0); wraps for y0 / x0 = -1, where it is only ever used with a valid tap's offset added
+            voff_a[i] = ((unsigned)((img * p.H + y0) * p.Wd + x0) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                if (m < p.M && y0 + t >= 0 && y0 + t < p.H) mk |= 1u << t;
+                if (x0 + t >= 0 && x0 + t < p.Wd) mk |= 8u << t;
+            }
+            amask |= mk << (6 * i);
+        }
+    } else {  // TEMPORAL3: m = (b*T + t)*S + s over [clips*T][S][Cin]; frames outside the window are the conv's zero padding
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)p.M * (unsigned)p.Cin * 2u), 0x00020000);
+        voff_a[0] = ((unsigned)(m0 + lr) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
+        apass = (unsigned)PRPP * (unsigned)p.Cin * 2u;
+#pragma unroll
+        for (int i = 0; i < PAP; ++i) {
+            const int m = m0 + lr + PRPP * i;
+            const int t = (m / p.S) % p.T;
+            if (m < p.M) amask |= ((t > 0 ? 1u : 0u) | 2u | (t + 1 < p.T ? 4u : 0u)) << (3 * i);
+        }
+    }
+
+    const int nk = p.K / BK;
+    int tap = 0, c0b = 0;   // (tap, channel-slab byte offset) of the NEXT K-step to stage (conv loaders: K-step = (slab kt / NTAPS, tap kt % NTAPS))
+    int kb = 0;             // its byte offset inside a weight row (dense: also inside an activation row)
+
+    // piece i (i < 5: 64 weight rows, else 64 activation rows) of the next K-step into `stage`; dma_next() after a tile's last piece
+    auto dma_piece = [&](const int i, const int stage) __attribute__((always_inline)) {
+        char* const sA = smem + stage * PSTAGE + wave_u * 1024;
+        if (i < PWP) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lptr_t)(sA + PA_BYTES + i * PRPP * 128), 16, voff_w, (unsigned)i * wpass + (unsigned)kb, 0, 0);
+            return;
+        }
+        const int j = i - PWP;
+        lptr_t dst = (lptr_t)(sA + j * PRPP * 128);
+        if (AMODE == AMODE_DENSE) {
+            const unsigned v = voff_a[0] + (unsigned)j * apass;   // (the row term stays in the bounds-checked part of the address: rows past M read zeros)
+            if (NT_A) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, v, (unsigned)kb, 0, 2);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, v, (unsigned)kb, 0, 0);
+        } else if (AMODE == AMODE_CONV3X3) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const unsigned tapoff = (unsigned)((ky * p.Wd + kx) * p.Cin) * 2u;
+            const bool ok = ((amask >> (6 * j + ky)) & (amask >> (6 * j + 3 + kx)) & 1u) != 0;
+            const unsigned v = ok ? voff_a[j] + tapoff : P_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, v, (unsigned)c0b, 0, 0);
+        } else {
+            const unsigned tapoff = (unsigned)((tap - 1) * p.S * p.Cin) * 2u;
+            const bool ok = ((amask >> (3 * j + tap)) & 1u) != 0;
+            const unsigned v = ok ? voff_a[0] + (unsigned)j * apass + tapoff : P_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, v, (unsigned)c0b, 0, 0);
+        }
+    };
+    auto dma_next = [&]() __attribute__((always_inline)) {
+        kb += BK * 2;
+        if (AMODE != AMODE_DENSE) {
+            if (++tap == NTAPS) { tap = 0; c0b += BK * 2; }
+        }
+    };
+
+    f32x16_t acc[PFX][PFY];
+#pragma unroll
+    for (int i = 0; i < PFX; ++i)
+#pragma unroll
+        for (int j = 0; j < PFY; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: weights rows wn*160 + 32*f + l31 of sW, activation rows wm*64 + 32*f + l31 of sA, k-substep ks = chunk (2*ks + lh) ^ sw
+    const int sw = (l31 >> 1) & 7;
+    const int xrow = PA_BYTES + (wn * 160 + l31) * 128, yrow = (wm * 64 + l31) * 128;
+    auto load_frags = [&](const int stage, const int ks, bf16x8_t* xf, bf16x8_t* yf) __attribute__((always_inline)) {
+        const char* sb = smem + stage * PSTAGE + ((((ks * 2 + lh) ^ sw)) << 4);
+#pragma unroll
+        for (int f = 0; f < PFY; ++f) yf[f] = *(const bf16x8_t*)(sb + yrow + f * 32 * 128);
+#pragma unroll
+        for (int f = 0; f < PFX; ++f) xf[f] = *(const bf16x8_t*)(sb + xrow + f * 32 * 128);
+    };
+    auto mma = [&](const bf16x8_t* xf, const bf16x8_t* yf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int fi = 0; fi < PFX; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+    };
+    // ten MFMAs of one k-substep with pieces p0 .. p0 + np - 1 of the next tile, one after every MFMA pair
+    auto mma_dma = [&](const bf16x8_t* xf, const bf16x8_t* yf, const int p0, const int np, const int stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int fi = 0; fi < PFX; ++fi) {
+#pragma unroll
+            for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+            if (fi < np) {
+                PIPE_SB();
+                dma_piece(p0 + fi, stage);
+                PIPE_SB();
+            }
+        }
+    };
+
+    // ---- prologue: the first tile's nine pieces, then (under them) the epilogue's vectors and the folded LayerNorm's row statistics ----
+    float2* const lnrow = (float2*)(smem + LN_OFF);
+    float* const epi_vec = (float*)(smem + EV_OFF);
+    const EpiPlan eplan = epi_plan<EPI_LINEAR, false, PBM, PBN>(p, m0, n0);
+#pragma unroll
+    for (int i = 0; i < PWP + PAP; ++i) dma_piece(i, 0);
+    dma_next();
+    if (eplan.fast) epi_stage_vectors<PBN, PNT>(p, epi_vec, n0, eplan, tid);
+    if (p.ln_stats != nullptr) {
+        for (int r = tid; r < PBM; r += PNT) {
+            const int m = m0 + r;
+            lnrow[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
+        }
+    }
+    __syncthreads();
+
+    bf16x8_t xa[PFX], ya[PFY], xb[PFX], yb[PFY];
+    load_frags(0, 0, xa, ya);
+    load_frags(0, 1, xb, yb);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        const int stage = kt & 1;
+        PIPE_SB();
+        mma_dma(xa, ya, 0, 5, stage ^ 1);
+        PIPE_SB();
+        load_frags(stage, 2, xa, ya);
+        PIPE_SB();
+        mma_dma(xb, yb, 5, 4, stage ^ 1);
+        dma_next();
+        PIPE_SB();
+        load_frags(stage, 3, xb, yb);
+        PIPE_SB();
+        mma(xa, ya);
+        PIPE_SB();
+        __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 have landed; lgkmcnt(0): its reads of stage kt are done
+        load_frags(stage ^ 1, 0, xa, ya);
+        PIPE_SB();
+        mma(xb, yb);
+        PIPE_SB();
+        load_frags(stage ^ 1, 1, xb, yb);
+    }
+    {   // last K-step: nothing left to stage
+        const int stage = (nk - 1) & 1;
+        PIPE_SB();
+        mma(xa, ya);
+        PIPE_SB();
+        load_frags(stage, 2, xa, ya);
+        PIPE_SB();
+        mma(xb, yb);
+        PIPE_SB();
+        load_frags(stage, 3, xb, yb);
+        PIPE_SB();
+        mma(xa, ya);
+        PIPE_SB();
+        mma(xb, yb);
+    }
+
+    if (eplan.fast) gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, p.ln_stats != nullptr ? lnrow : nullptr, epi_vec, eplan.img0);
+    else gemm_epilogue<EPI_LINEAR, false, PFX, PFY, 2, 5>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, p.ln_stats != nullptr ? lnrow : nullptr);
+}
+
+template <int AMODE>
+int pipe_launch(const VkGemmDesc* d, hipStream_t stream) {
+    const int tilesN = d->N / PBN, tilesM = (d->M + PBM - 1) / PBM;
+    VkGemmDesc desc = *d;
+    const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally
+    if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, AMODE == AMODE_DENSE>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, false>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
+}  // namespace
+
+// 1 = the pipelined variant takes this (already validated) problem
+extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d) {
+    if (d->epi != EPI_LINEAR || d->out_f32 || (d->N % PBN) != 0 || d->mx8_out || d->A2) return 0;
+    if ((unsigned long long)PBN * d->K * 2ull >= P_LIMIT) return 0;
+    if (d->amode == AMODE_DENSE) return ((unsigned long long)PBM * d->lda * 2ull < P_LIMIT) ? 1 : 0;
+    if (d->amode == AMODE_CONV3X3) {
+        if (d->ups != 1) return 0;   // the fused nearest x2 upsample's source pixel is not affine in the tap
+        const long long hw = (long long)d->Hout * d->Wout;
+        if (hw <= 0 || (d->M % hw) != 0) return 0;
+        return ((unsigned long long)(d->M / hw) * d->H * d->Wd * d->Cin * 2ull < P_LIMIT) ? 1 : 0;
+    }
+    if (d->amode == AMODE_TEMPORAL3) {
+        if (d->halo_prev || d->halo_next) return 0;   // neighbour ranks' halo frames are other tensors: the sixteen-wave kernel's per-lane pointers
+        return ((unsigned long long)d->M * d->Cin * 2ull < P_LIMIT) ? 1 : 0;
+    }
+    return 0;
+}
+
+extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!vk_gemm_pipe_fit(d)) return VK_EINVAL;
+#ifndef VK_PIPE_ONLY   // (-DVK_PIPE_ONLY=<amode>: a one-loader build for tuning sessions)
+#define VK_PIPE_ONLY -1
+#endif
+    constexpr int only = VK_PIPE_ONLY;
+    if constexpr (only < 0 || only == AMODE_DENSE) if (d->amode == AMODE_DENSE) return pipe_launch<AMODE_DENSE>(d, stream);
+    if constexpr (only < 0 || only == AMODE_CONV3X3) if (d->amode == AMODE_CONV3X3) return pipe_launch<AMODE_CONV3X3>(d, stream);
+    if constexpr (only < 0 || only == AMODE_TEMPORAL3) if (d->amode == AMODE_TEMPORAL3) return pipe_launch<AMODE_TEMPORAL3>(d, stream);
+    return VK_EINVAL;
+}
