@@ -447,8 +447,8 @@ def test_gemm_launch_rules_are_pinned():
     assert choice(full, 960, 320) == (7, 1)                     # q|k|v: N = 3K
     assert choice(full, 320, 1280, stats=True) == (7, 1)        # FeedForward out: K = 4N
     assert choice(full, 2560, 320, epi=ops.EPI_GEGLU) == (3, 1)
-    assert choice(L1, 5120, 640, epi=ops.EPI_GEGLU) == (4, 1)   # 256x320 since the LDS-staged epilogue (K >= 640); sixteen waves (the pipelined kernel has no GEGLU epilogue)
-    assert choice(L2, 10240, 1280, epi=ops.EPI_GEGLU) == (3, 1)
+    assert choice(L1, 5120, 640, epi=ops.EPI_GEGLU) == (7, 1)   # K >= 640: the pipelined 256x320 kernel
+    assert choice(L2, 10240, 1280, epi=ops.EPI_GEGLU) == (7, 1)
     assert choice(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128) == (7, 1)
     assert choice(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, tile_cfg=4) == (4, 1)   # forced: the sixteen-wave kernel
     # one rank of 8 (7 images)
@@ -457,7 +457,7 @@ def test_gemm_launch_rules_are_pinned():
     assert choice(r1, 640, 640, stats=True) == (5, 1)           # 126 tiles of 256x320 would fill half the chip
     assert choice(r1, 640, 2560, stats=True) == (5, 1)
     assert choice(r2, 1280, 5120, stats=True) == (5, 1)
-    assert choice(r2, 10240, 1280, epi=ops.EPI_GEGLU) == (4, 1)  # 512 tiles = 2 rounds instead of 640 = 3
+    assert choice(r2, 10240, 1280, epi=ops.EPI_GEGLU) == (7, 1)  # 512 tiles of 256x320 = 2 rounds instead of 640 = 3
     cfg, ks = choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32)
     assert cfg == 4 and ks >= 2, "small-M deep-K convolutions run split-K on the big tile"
     assert choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32, ws=False) [1] == 1  # no workspace, no split

@@ -20,7 +20,8 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     rn = lambda *s: torch.randn(*s, device="cuda")  # noqa: E731
     bad = 0
-    for C, H, W, n in ((320, 72, 128, N), (640, 36, 64, N), (1280, 18, 32, N), (320, 20, 24, 3), (640, 9, 13, 5)):
+    shapes = ((320, 72, 128, N), (640, 36, 64, N), (1280, 18, 32, N), (320, 20, 24, 3), (640, 9, 13, 5))
+    for C, H, W, n in (shapes[:3] if os.environ.get("PROBE_FAST") else shapes):
         T = 25 if n % 25 == 0 else n
         M = n * H * W
         x = rn(M, C).to(BF16)
@@ -36,6 +37,8 @@ def main():
             "ff_out+res+stats": (lambda pw=ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C)): ops.linear(h4, pw, res1=res, emit_stats=True), 2.0 * M * 4 * C * C),
             "ff_out+blend": (lambda pw=ops.pack_linear(rn(C, 4 * C) * (4 * C) ** -0.5, rn(C)): ops.linear(
                 h4, pw, res1=res, alpha=0.4, res2=x, rowvec2=rv, beta=0.6, rows_per_vec=H * W), 2.0 * M * 4 * C * C),
+            "geglu_lnfold": (lambda pw=ops.pack_geglu(rn(8 * C, C) * C ** -0.5, rn(8 * C), ln=nrm): ops.linear(x, pw, ln=st), 2.0 * M * 8 * C * C),
+            "geglu_plain": (lambda pw=ops.pack_geglu(rn(8 * C, C) * C ** -0.5, rn(8 * C)): ops.linear(x, pw), 2.0 * M * 8 * C * C),
             "conv3x3": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, n, H, W), 2.0 * M * 9 * C * C),
             "conv3x3+emb+res": (lambda pw=ops.pack_conv3x3(rn(C, C, 3, 3) * (9 * C) ** -0.5, rn(C)): ops.conv3x3(x3, pw, n, H, W, rowvec=rv, res1=x3), 2.0 * M * 9 * C * C),
             "conv_t3": (lambda pw=ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C)): ops.conv_t3(x3, pw, T, H * W), 2.0 * M * 3 * C * C),
@@ -51,13 +54,22 @@ def main():
             bad += not same
             ms = {}
             for _ in range(3):
-                for cfg in (4, 7):
+                for cfg in (4, 7) + ((3,) if name.startswith("geglu") else ()):
                     ops.TILE_CFG = cfg
                     ms[cfg] = min(ms.get(cfg, 1e9), timeit(fn))
             ops.TILE_CFG = 0
+            if os.environ.get("PROBE_TIMING"):   # library built with -DPIPE_TIMING: per-wave s_memtime sums of workgroup 8
+                ops.TILE_CFG = 7
+                fn()
+                torch.cuda.synchronize()
+                ws = ops._splitk_workspace(ops._stream())[:64].view(8, 8).cpu()
+                ops.TILE_CFG = 0
+                for w in (0, 5):
+                    d, b, per, ks, pro, loop, epi = ws[w, :7].tolist()
+                    print(f"      wave {w}: K-steps {int(ks) + 2}  period {per / max(ks, 1):.0f}  own-DMA wait {d / (ks + 1):.0f}  barrier wait {b / (ks + 1):.0f} per K-step;  prologue {pro:.0f}  loop {loop:.0f}  epilogue {epi:.0f} ticks")
             err = max((a.float() - b.float()).abs().max().item() for a, b in zip(out[4], out[7]))
             print(f"C {C:5d} M {M:7d} {name:18s} bitwise {'OK ' if same else 'DIFF'} max|d| {err:.3g}   cfg4 {ms[4]:.4f} ms  cfg7 {ms[7]:.4f} ms  "
-                  f"{100 * (ms[4] / ms[7] - 1):+.1f} %   {flop / ms[7] / 1e9:.0f} TFLOP/s", flush=True)
+                  f"{100 * (ms[4] / ms[7] - 1):+.1f} %   {flop / ms[7] / 1e9:.0f} TFLOP/s" + (f"   cfg3 {ms[3]:.4f} ms" if 3 in ms else ""), flush=True)
         del x, res, h4, cases
         torch.cuda.empty_cache()
     print("MISMATCHES", bad)

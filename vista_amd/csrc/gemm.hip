@@ -508,6 +508,10 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     // sweep +14-17 % on the 3x3 convs, +5-15 % on the dense / temporal shapes, bitwise the same results). VISTA_GEMM_PIPE=0: A/B hook.
     static const bool pipe_on = [] { const char* e = getenv("VISTA_GEMM_PIPE"); return !e || atoi(e) != 0; }();
     if (cfg == 4 && ksplit == 1 && force == 0 && pipe_on && vk_gemm_pipe_fit(d)) cfg = 7;
+    // GEGLU: +10-11 % at level 1 and +16-17 % at level 2 over the better of 256x256 / 256x320 (sixteen waves), also on one rank's small
+    // problems; K = 320 (level 0 without the fused FeedForward) stays on the persistent 256x256 kernel, where the pipelined one is 5 % behind
+    if (epi == EPI_GEGLU && (cfg == 3 || cfg == 4) && force == 0 && pipe_on && d->K >= 640 && vk_gemm_pipe_fit(d)) cfg = 7;
+    if (epi == EPI_GEGLU && cfg == 7 && force == 0 && d->K < 640) cfg = 3;
     return {cfg, ksplit};
 }
 

@@ -36,12 +36,16 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int AMODE, bool NT_A>
+template <int AMODE, int EPI, bool NT_A>
 __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     constexpr int LN_OFF = 2 * PSTAGE, EV_OFF = LN_OFF + PBM * 8;
     constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
     __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE + PBM * 8 + epi_vec_floats(PBN) * 4];
 
+#ifdef PIPE_TIMING
+    unsigned long long tm_k0;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_k0) :: "memory");
+#endif
     const int tilesN = p.N / PBN;
     const int tilesM = (p.M + PBM - 1) / PBM;
     const int ntiles = tilesM * tilesN;
@@ -178,15 +182,33 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
 #pragma unroll
             for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
     };
+#ifndef PIPE_AFIRST
+#define PIPE_AFIRST 1
+#endif
+#ifndef PIPE_SCHED
+#define PIPE_SCHED 1
+#endif
+    // q-th piece of a tile in issue order
+    auto dma_q = [&](const int q, const int stage) __attribute__((always_inline)) {
+        if (PIPE_AFIRST) dma_piece(q < PAP ? PWP + q : q - PAP, stage);
+        else dma_piece(q, stage);
+    };
     // ten MFMAs of one k-substep with pieces p0 .. p0 + np - 1 of the next tile, one after every MFMA pair
     auto mma_dma = [&](const bf16x8_t* xf, const bf16x8_t* yf, const int p0, const int np, const int stage) __attribute__((always_inline)) {
 #pragma unroll
         for (int fi = 0; fi < PFX; ++fi) {
 #pragma unroll
-            for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
-            if (fi < np) {
+            for (int fj = 0; fj < PFY; ++fj) {
+                acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+                if (PIPE_SCHED == 1 && fi * 2 + fj < np) {
+                    PIPE_SB();
+                    dma_q(p0 + fi * 2 + fj, stage);
+                    PIPE_SB();
+                }
+            }
+            if (PIPE_SCHED == 0 && fi < np) {
                 PIPE_SB();
-                dma_piece(p0 + fi, stage);
+                dma_q(p0 + fi, stage);
                 PIPE_SB();
             }
         }
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     // ---- prologue: the first tile's nine pieces, then (under them) the epilogue's vectors and the folded LayerNorm's row statistics ----
     float2* const lnrow = (float2*)(smem + LN_OFF);
     float* const epi_vec = (float*)(smem + EV_OFF);
-    const EpiPlan eplan = epi_plan<EPI_LINEAR, false, PBM, PBN>(p, m0, n0);
+    const EpiPlan eplan = epi_plan<EPI, false, PBM, PBN>(p, m0, n0);
 #pragma unroll
     for (int i = 0; i < PWP + PAP; ++i) dma_piece(i, 0);
     dma_next();
@@ -208,24 +230,42 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     }
     __syncthreads();
 
+#ifdef PIPE_TIMING
+    unsigned long long tm_dma = 0, tm_bar = 0, tm_per = 0, tm_last = 0, tm_start;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_start) :: "memory");
+#endif
     bf16x8_t xa[PFX], ya[PFY], xb[PFX], yb[PFY];
     load_frags(0, 0, xa, ya);
     load_frags(0, 1, xb, yb);
     for (int kt = 0; kt + 1 < nk; ++kt) {
         const int stage = kt & 1;
         PIPE_SB();
-        mma_dma(xa, ya, 0, 5, stage ^ 1);
+        if (PIPE_SCHED == 2) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) dma_q(q, stage ^ 1);
+            PIPE_SB();
+        }
+        mma_dma(xa, ya, 0, PIPE_SCHED == 0 ? 5 : PIPE_SCHED == 1 ? 9 : 0, stage ^ 1);
         PIPE_SB();
         load_frags(stage, 2, xa, ya);
         PIPE_SB();
-        mma_dma(xb, yb, 5, 4, stage ^ 1);
+        mma_dma(xb, yb, 5, PIPE_SCHED == 0 ? 4 : 0, stage ^ 1);
         dma_next();
         PIPE_SB();
         load_frags(stage, 3, xb, yb);
         PIPE_SB();
         mma(xa, ya);
         PIPE_SB();
+#ifdef PIPE_TIMING   // s_memtime stamps around the barrier (tools/gemm_pipe_probe.py --timing): barrier wait, own DMA wait and the K-step period
+        unsigned long long t1, t2, t3;
+        asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
+#endif
         __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 have landed; lgkmcnt(0): its reads of stage kt are done
+#ifdef PIPE_TIMING
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t3) :: "memory");
+        tm_dma += t2 - t1; tm_bar += t3 - t2; if (kt > 0) tm_per += t1 - tm_last; tm_last = t1;
+#endif
         load_frags(stage ^ 1, 0, xa, ya);
         PIPE_SB();
         mma(xb, yb);
@@ -248,17 +288,35 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
         mma(xb, yb);
     }
 
-    if (eplan.fast) gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, p.ln_stats != nullptr ? lnrow : nullptr, epi_vec, eplan.img0);
-    else gemm_epilogue<EPI_LINEAR, false, PFX, PFY, 2, 5>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, p.ln_stats != nullptr ? lnrow : nullptr);
+#ifdef PIPE_TIMING
+    unsigned long long tm_loop_end;
+    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_loop_end) :: "memory");
+#endif
+    const float2* const lnp = p.ln_stats != nullptr ? lnrow : nullptr;
+    if constexpr (EPI == EPI_GEGLU) {
+        if (eplan.fast) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, wm, wn, l31, lh, lnp, epi_vec);
+        else gemm_epilogue<EPI_GEGLU, false, PFX, PFY, 2, 5>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, lnp);
+    } else {
+        if (eplan.fast) gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, lnp, epi_vec, eplan.img0);
+        else gemm_epilogue<EPI_LINEAR, false, PFX, PFY, 2, 5>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, lnp);
+    }
+#ifdef PIPE_TIMING
+    if (blockIdx.x == 8 && lane == 0 && p.splitk_ws) {   // per wave: [DMA wait, barrier wait, K-step period sum, K-steps - 1, prologue, loop, epilogue]
+        unsigned long long tm_end;
+        asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_end) :: "memory");
+        float* o = (float*)p.splitk_ws + wave * 8;
+        o[0] = (float)tm_dma; o[1] = (float)tm_bar; o[2] = (float)tm_per; o[3] = (float)(nk - 2); o[4] = (float)(tm_start - tm_k0); o[5] = (float)(tm_loop_end - tm_start); o[6] = (float)(tm_end - tm_loop_end);
+    }
+#endif
 }
 
-template <int AMODE>
+template <int AMODE, int EPI>
 int pipe_launch(const VkGemmDesc* d, hipStream_t stream) {
     const int tilesN = d->N / PBN, tilesM = (d->M + PBM - 1) / PBM;
     VkGemmDesc desc = *d;
     const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally
-    if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, AMODE == AMODE_DENSE>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
-    else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, false>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
+    if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, AMODE == AMODE_DENSE>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
@@ -267,7 +325,8 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream) {
 
 // 1 = the pipelined variant takes this (already validated) problem
 extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d) {
-    if (d->epi != EPI_LINEAR || d->out_f32 || (d->N % PBN) != 0 || d->mx8_out || d->A2) return 0;
+    if ((d->epi != EPI_LINEAR && d->epi != EPI_GEGLU) || d->out_f32 || (d->N % PBN) != 0 || d->mx8_out || d->A2) return 0;
+    if (d->epi == EPI_GEGLU && d->amode != AMODE_DENSE) return 0;
     if ((unsigned long long)PBN * d->K * 2ull >= P_LIMIT) return 0;
     if (d->amode == AMODE_DENSE) return ((unsigned long long)PBM * d->lda * 2ull < P_LIMIT) ? 1 : 0;
     if (d->amode == AMODE_CONV3X3) {
@@ -290,8 +349,9 @@ extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream_) {
 #define VK_PIPE_ONLY -1
 #endif
     constexpr int only = VK_PIPE_ONLY;
-    if constexpr (only < 0 || only == AMODE_DENSE) if (d->amode == AMODE_DENSE) return pipe_launch<AMODE_DENSE>(d, stream);
-    if constexpr (only < 0 || only == AMODE_CONV3X3) if (d->amode == AMODE_CONV3X3) return pipe_launch<AMODE_CONV3X3>(d, stream);
-    if constexpr (only < 0 || only == AMODE_TEMPORAL3) if (d->amode == AMODE_TEMPORAL3) return pipe_launch<AMODE_TEMPORAL3>(d, stream);
+    if constexpr (only < 0 || only == AMODE_DENSE) if (d->amode == AMODE_DENSE)
+        return d->epi == EPI_GEGLU ? pipe_launch<AMODE_DENSE, EPI_GEGLU>(d, stream) : pipe_launch<AMODE_DENSE, EPI_LINEAR>(d, stream);
+    if constexpr (only < 0 || only == AMODE_CONV3X3) if (d->amode == AMODE_CONV3X3) return pipe_launch<AMODE_CONV3X3, EPI_LINEAR>(d, stream);
+    if constexpr (only < 0 || only == AMODE_TEMPORAL3) if (d->amode == AMODE_TEMPORAL3) return pipe_launch<AMODE_TEMPORAL3, EPI_LINEAR>(d, stream);
     return VK_EINVAL;
 }
