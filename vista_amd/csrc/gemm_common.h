@@ -359,6 +359,25 @@ __device__ __forceinline__ EpiPlan epi_plan(const VkGemmDesc& p, int m0, int n0)
     return e;
 }
 
+// The tile-independent part of epi_plan for a launch whose N is a multiple of the tile width, as host + device code: true = EVERY tile of the
+// launch takes the LDS-staged epilogue (kernels that carry no general epilogue -- gemm_pipe.hip -- take only such launches). Keep in step with epi_plan.
+__host__ __device__ inline bool epi_fast_everywhere(const VkGemmDesc& p, int epi, int bm) {
+    if (p.out_f32 || epi == EPI_TRANS) return false;
+    if ((p.ldc % 8) != 0 || (((size_t)p.out) & 15) != 0) return false;
+    const unsigned long long lim = 0xfffff000ull, rows = (unsigned long long)p.M * 2ull;
+    if (rows * (unsigned)p.ldc >= lim || (p.res1 && rows * (unsigned)p.ld_res1 >= lim) || (p.res2 && rows * (unsigned)p.ld_res2 >= lim)) return false;
+    if (p.bias && (((size_t)p.bias) & 15) != 0) return false;
+    if (p.ln_stats && (((size_t)p.ln_colsum) & 15) != 0) return false;
+    if (epi == EPI_GEGLU) return true;
+    if (p.res1 && ((p.ld_res1 % 8) != 0 || (((size_t)p.res1) & 15) != 0)) return false;
+    if (p.res2 && ((p.ld_res2 % 8) != 0 || (((size_t)p.res2) & 15) != 0)) return false;
+    if (p.rowvec || p.rowvec2) {
+        if ((p.ldv % 4) != 0 || (p.rowvec && (((size_t)p.rowvec) & 15) != 0) || (p.rowvec2 && (((size_t)p.rowvec2) & 15) != 0)) return false;
+        if ((bm - 1) / p.rows_per_vec + 2 > EPI_NI) return false;   // bm consecutive rows span at most (bm - 1) / rows_per_vec + 2 images
+    }
+    return true;
+}
+
 // one float4 per thread: section s of the region = [bias | colsum | rowvec of images img0.. | rowvec2 of images img0..], absent ones zero
 template <int BN, int NT>
 __device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev, int n0, const EpiPlan& e, int tid) {

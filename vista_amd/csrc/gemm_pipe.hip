@@ -3,8 +3,8 @@
 // same -- but the K-step is written for the matrix pipe instead of for occupancy:
 //   * eight waves, wave tile 64 x 160 (2 activation x 5 weight fragments, 160 accumulator registers, 256-VGPR budget, two waves per SIMD):
 //     7 ds_read_b128 per 10 MFMAs instead of 6 per 5;
-//   * fragments double-buffered ACROSS the K-step barrier: the last k-substep's ten MFMAs are issued after the barrier and cover the first
-//     fragment reads of the next stage, so no LDS latency is exposed anywhere in the loop (the sixteen-wave kernel waits on lgkmcnt(0) before
+//   * fragments double-buffered ACROSS the K-step barrier: the last k-substep's ten MFMAs are issued after the barrier and
+//     cover the first fragment reads of the next stage, so no LDS latency is exposed anywhere in the loop (the sixteen-wave kernel waits on lgkmcnt(0) before
 //     almost every MFMA pair and relies on its four waves per SIMD to fill the holes);
 //   * the nine LDS-DMA pieces of the next tile are issued BETWEEN the MFMAs of the first two k-substeps, one per MFMA pair. An LDS-DMA issue
 //     stalls its wave for ~120 cycles (profiles/r04_ff_fused_notes.txt); at the head of the K-step, where the other variants issue them, both
@@ -40,12 +40,13 @@ template <int AMODE, int EPI, bool NT_A>
 __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     constexpr int LN_OFF = 2 * PSTAGE, EV_OFF = LN_OFF + PBM * 8;
     constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
+    constexpr bool WALK = (EPI == EPI_GEGLU);   // persistent tile walk (pipe_launch); the LINEAR instantiations are compiled as one tile per workgroup
     __shared__ __attribute__((aligned(16))) char smem[2 * PSTAGE + PBM * 8 + epi_vec_floats(PBN) * 4];
-
 #ifdef PIPE_TIMING
-    unsigned long long tm_k0;
+    unsigned long long tm_k0, tm_dma = 0, tm_bar = 0, tm_loop = 0, tm_epi = 0, tm_ksteps = 0;
     asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_k0) :: "memory");
 #endif
+
     const int tilesN = p.N / PBN;
     const int tilesM = (p.M + PBM - 1) / PBM;
     const int ntiles = tilesM * tilesN;
@@ -53,79 +54,80 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int logical = xcd_remap(blockIdx.x, ntiles);
-    int tn, tm;   // tile order: as gemm.hip (column tile fastest unless the weights overflow the L2)
-    if (tilesN < 8 || (long long)p.N * p.K * 2 <= (3LL << 20)) {
-        tn = logical % tilesN;
-        tm = logical / tilesN;
-    } else {
-        constexpr int GM = 8;
-        const int panel = logical / (GM * tilesN), r = logical - panel * (GM * tilesN);
-        const int gm = (tilesM - panel * GM < GM) ? tilesM - panel * GM : GM;
-        tm = panel * GM + r % gm;
-        tn = r / gm;
-    }
-    const int m0 = tm * PBM, n0 = tn * PBN;
+    // tile order: as gemm.hip (column tile fastest unless the weights overflow the L2, then panels of 8 row tiles). The launch is
+    // PERSISTENT: workgroup b walks tiles b, b + gridDim.x, ... (gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so a
+    // workgroup's tiles stay in its XCD's range of the remap)
+    auto tile_of = [&](const int bid, int& tm, int& tn) __attribute__((always_inline)) {
+        const int logical = xcd_remap(bid, ntiles);
+        if (tilesN < 8 || (long long)p.N * p.K * 2 <= (3LL << 20)) {
+            tn = logical % tilesN;
+            tm = logical / tilesN;
+        } else {
+            constexpr int GM = 8;
+            const int panel = logical / (GM * tilesN), r = logical - panel * (GM * tilesN);
+            const int gm = (tilesM - panel * GM < GM) ? tilesM - panel * GM : GM;
+            tm = panel * GM + r % gm;
+            tn = r / gm;
+        }
+    };
 
     // ---- staging assignment: 16-byte chunk lc of tile rows lr + 64 * i; the XOR swizzle lives in the SOURCE chunk index (gemm.hip) ----
     const int lc = tid & 7, lr = tid >> 3;
     const int lsrc = lc ^ ((lr >> 1) & 7);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    // weights: rows n0 .. n0 + 319 of W[N][K]
-    const __amdgpu_buffer_rsrc_t rw =
-        __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.Wt + (size_t)n0 * p.K), 0, (int)((unsigned)PBN * (unsigned)p.K * 2u), 0x00020000);
     const unsigned voff_w = ((unsigned)lr * (unsigned)p.K + (unsigned)lsrc * 8u) * 2u;
     const unsigned wpass = (unsigned)PRPP * (unsigned)p.K * 2u;   // bytes between the row groups of two weight pieces
+    const unsigned apass = (unsigned)PRPP * (unsigned)(AMODE == AMODE_DENSE ? p.lda : p.Cin) * 2u;   // DENSE / TEMPORAL3: ... of two activation pieces
 
-    // activations: a resource, per-lane offsets of the row groups, validity bits
-    __amdgpu_buffer_rsrc_t ra;
-    unsigned voff_a[PAP];   // DENSE / TEMPORAL3: [0] only (the row groups are a uniform stride `apass` apart)
+    // address state of the tile being staged: a resource per operand, per-lane offsets of the activation row groups, validity bits
+    __amdgpu_buffer_rsrc_t rw, ra;
+    unsigned voff_a[PAP];   // DENSE / TEMPORAL3: [0] only (the row groups are the uniform stride `apass` apart)
     unsigned amask = 0;     // CONV3X3: per piece 3 row-valid + 3 column-valid bits (tap (ky, kx) valid = row bit ky & column bit kx); TEMPORAL3: 3 frame bits
-    unsigned apass = 0;
-    if (AMODE == AMODE_DENSE) {
-        const int rows = (p.M - m0 < PBM) ? p.M - m0 : PBM;
-        ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.A + (size_t)m0 * p.lda), 0,
-                                               (int)(((unsigned)(rows - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u), 0x00020000);
-        voff_a[0] = ((unsigned)lr * (unsigned)p.lda + (unsigned)lsrc * 8u) * 2u;
-        apass = (unsigned)PRPP * (unsigned)p.lda * 2u;
-    } else if (AMODE == AMODE_CONV3X3) {
-        const int hw = p.Hout * p.Wout;
-        ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)(p.M / hw) * (unsigned)(p.H * p.Wd) * (unsigned)p.Cin * 2u), 0x00020000);
+    auto setup = [&](const int m0, const int n0) __attribute__((always_inline)) {
+        rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.Wt + (size_t)n0 * p.K), 0, (int)((unsigned)PBN * (unsigned)p.K * 2u), 0x00020000);
+        amask = 0;
+        if (AMODE == AMODE_DENSE) {
+            const int rows = (p.M - m0 < PBM) ? p.M - m0 : PBM;
+            ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.A + (size_t)m0 * p.lda), 0,
+                                                   (int)(((unsigned)(rows - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u), 0x00020000);
+            voff_a[0] = ((unsigned)lr * (unsigned)p.lda + (unsigned)lsrc * 8u) * 2u;
+        } else if (AMODE == AMODE_CONV3X3) {
+            const int hw = p.Hout * p.Wout;
+            ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)(p.M / hw) * (unsigned)(p.H * p.Wd) * (unsigned)p.Cin * 2u), 0x00020000);
 #pragma unroll
-        for (int i = 0; i < PAP; ++i) {
-            const int m = m0 + lr + PRPP * i;
-            const int img = m / hw;
-            const int rem = m - img * hw;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            const int y0 = oy * p.stride - (p.asym_pad ? 0 : 1), x0 = ox * p.stride - (p.asym_pad ? 0 : 1);
-            // tap (0, 0); wraps for y0 / x0 = -1, where it is only ever used with a valid tap's offset added
-            voff_a[i] = ((unsigned)((img * p.H + y0) * p.Wd + x0) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
-            unsigned mk = 0;
+            for (int i = 0; i < PAP; ++i) {
+                const int m = m0 + lr + PRPP * i;
+                const int img = m / hw;
+                const int rem = m - img * hw;
+                const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                const int y0 = oy * p.stride - (p.asym_pad ? 0 : 1), x0 = ox * p.stride - (p.asym_pad ? 0 : 1);
+                // tap (0, 0); wraps for y0 / x0 = -1, where it is only ever used with a valid tap's offset added
+                voff_a[i] = ((unsigned)((img * p.H + y0) * p.Wd + x0) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
+                unsigned mk = 0;
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                if (m < p.M && y0 + t >= 0 && y0 + t < p.H) mk |= 1u << t;
-                if (x0 + t >= 0 && x0 + t < p.Wd) mk |= 8u << t;
+                for (int t = 0; t < 3; ++t) {
+                    if (m < p.M && y0 + t >= 0 && y0 + t < p.H) mk |= 1u << t;
+                    if (x0 + t >= 0 && x0 + t < p.Wd) mk |= 8u << t;
+                }
+                amask |= mk << (6 * i);
             }
-            amask |= mk << (6 * i);
-        }
-    } else {  // TEMPORAL3: m = (b*T + t)*S + s over [clips*T][S][Cin]; frames outside the window are the conv's zero padding
-        ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)p.M * (unsigned)p.Cin * 2u), 0x00020000);
-        voff_a[0] = ((unsigned)(m0 + lr) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
-        apass = (unsigned)PRPP * (unsigned)p.Cin * 2u;
+        } else {  // TEMPORAL3: m = (b*T + t)*S + s over [clips*T][S][Cin]; frames outside the window are the conv's zero padding
+            ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)p.M * (unsigned)p.Cin * 2u), 0x00020000);
+            voff_a[0] = ((unsigned)(m0 + lr) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
 #pragma unroll
-        for (int i = 0; i < PAP; ++i) {
-            const int m = m0 + lr + PRPP * i;
-            const int t = (m / p.S) % p.T;
-            if (m < p.M) amask |= ((t > 0 ? 1u : 0u) | 2u | (t + 1 < p.T ? 4u : 0u)) << (3 * i);
+            for (int i = 0; i < PAP; ++i) {
+                const int m = m0 + lr + PRPP * i;
+                const int t = (m / p.S) % p.T;
+                if (m < p.M) amask |= ((t > 0 ? 1u : 0u) | 2u | (t + 1 < p.T ? 4u : 0u)) << (3 * i);
+            }
         }
-    }
+    };
 
     const int nk = p.K / BK;
     int tap = 0, c0b = 0;   // (tap, channel-slab byte offset) of the NEXT K-step to stage (conv loaders: K-step = (slab kt / NTAPS, tap kt % NTAPS))
     int kb = 0;             // its byte offset inside a weight row (dense: also inside an activation row)
 
-    // piece i (i < 5: 64 weight rows, else 64 activation rows) of the next K-step into `stage`; dma_next() after a tile's last piece
+    // piece i (i < 5: 64 weight rows, else 64 activation rows) of the next K-step into `stage`; dma_next() after a K-step's last piece
     auto dma_piece = [&](const int i, const int stage) __attribute__((always_inline)) {
         char* const sA = smem + stage * PSTAGE + wave_u * 1024;
         if (i < PWP) {
@@ -157,14 +159,10 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
             if (++tap == NTAPS) { tap = 0; c0b += BK * 2; }
         }
     };
+    // q-th piece of a K-step in issue order: the activation pieces first (they are the ones that may come from HBM)
+    auto dma_q = [&](const int q, const int stage) __attribute__((always_inline)) { dma_piece(q < PAP ? PWP + q : q - PAP, stage); };
 
     f32x16_t acc[PFX][PFY];
-#pragma unroll
-    for (int i = 0; i < PFX; ++i)
-#pragma unroll
-        for (int j = 0; j < PFY; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragment addresses: weights rows wn*160 + 32*f + l31 of sW, activation rows wm*64 + 32*f + l31 of sA, k-substep ks = chunk (2*ks + lh) ^ sw
     const int sw = (l31 >> 1) & 7;
@@ -182,130 +180,170 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
 #pragma unroll
             for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
     };
-#ifndef PIPE_AFIRST
-#define PIPE_AFIRST 1
-#endif
-#ifndef PIPE_SCHED
-#define PIPE_SCHED 1
-#endif
-    // q-th piece of a tile in issue order
-    auto dma_q = [&](const int q, const int stage) __attribute__((always_inline)) {
-        if (PIPE_AFIRST) dma_piece(q < PAP ? PWP + q : q - PAP, stage);
-        else dma_piece(q, stage);
-    };
-    // ten MFMAs of one k-substep with pieces p0 .. p0 + np - 1 of the next tile, one after every MFMA pair
-    auto mma_dma = [&](const bf16x8_t* xf, const bf16x8_t* yf, const int p0, const int np, const int stage) __attribute__((always_inline)) {
+    // the ten MFMAs of one k-substep with the nine pieces of the next K-step, one after each of the first nine MFMAs
+    auto mma_dma = [&](const bf16x8_t* xf, const bf16x8_t* yf, const int stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int fi = 0; fi < PFX; ++fi) {
+        for (int fi = 0; fi < PFX; ++fi)
 #pragma unroll
             for (int fj = 0; fj < PFY; ++fj) {
                 acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
-                if (PIPE_SCHED == 1 && fi * 2 + fj < np) {
+                if (fi * 2 + fj < PWP + PAP) {
                     PIPE_SB();
-                    dma_q(p0 + fi * 2 + fj, stage);
+                    dma_q(fi * 2 + fj, stage);
                     PIPE_SB();
                 }
             }
-            if (PIPE_SCHED == 0 && fi < np) {
-                PIPE_SB();
-                dma_q(p0 + fi, stage);
-                PIPE_SB();
+    };
+
+    float2* const lnrow = (float2*)(smem + LN_OFF);
+    float* const epi_vec = (float*)(smem + EV_OFF);
+    // every tile takes the LDS-staged epilogue (the host checked epi_fast_everywhere; this kernel carries no general one): only the images
+    // a tile's rows span remain to be found
+    auto plan_of = [&](const int m0) __attribute__((always_inline)) {
+        EpiPlan e{true, 0, 1};
+        if (EPI == EPI_LINEAR && (p.rowvec || p.rowvec2)) {
+            const int last = (m0 + PBM < p.M ? m0 + PBM : p.M) - 1;
+            e.img0 = m0 / p.rows_per_vec;
+            e.nimg = last / p.rows_per_vec - e.img0 + 1;
+        }
+        return e;
+    };
+    // a tile's epilogue vectors and folded-LayerNorm row statistics -> LDS (issued under the tile's first pieces)
+    auto stage_tile_vectors = [&](const int m0, const int n0, const EpiPlan& e) __attribute__((always_inline)) {
+        int tv = tid;
+        asm volatile("" : "+v"(tv));   // (as the epilogue: nothing lane-derived of this pass is to live across the K-loop)
+        epi_stage_vectors<PBN, PNT>(p, epi_vec, n0, e, tv);
+        if (p.ln_stats != nullptr) {
+            for (int r = tv; r < PBM; r += PNT) {
+                const int m = m0 + r;
+                lnrow[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
             }
         }
     };
 
-    // ---- prologue: the first tile's nine pieces, then (under them) the epilogue's vectors and the folded LayerNorm's row statistics ----
-    float2* const lnrow = (float2*)(smem + LN_OFF);
-    float* const epi_vec = (float*)(smem + EV_OFF);
-    const EpiPlan eplan = epi_plan<EPI, false, PBM, PBN>(p, m0, n0);
+    // ---- first tile: its first K-step's nine pieces, then (under them) the vectors ----
+    int bid = blockIdx.x;
+    int tm, tn;
+    tile_of(bid, tm, tn);
+    int m0 = tm * PBM, n0 = tn * PBN;
+    setup(m0, n0);
+    int st = 0;   // stage holding the current K-step
 #pragma unroll
-    for (int i = 0; i < PWP + PAP; ++i) dma_piece(i, 0);
+    for (int q = 0; q < PWP + PAP; ++q) dma_q(q, 0);
     dma_next();
-    if (eplan.fast) epi_stage_vectors<PBN, PNT>(p, epi_vec, n0, eplan, tid);
-    if (p.ln_stats != nullptr) {
-        for (int r = tid; r < PBM; r += PNT) {
-            const int m = m0 + r;
-            lnrow[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
-        }
-    }
+    EpiPlan eplan = plan_of(m0);
+    stage_tile_vectors(m0, n0, eplan);
     __syncthreads();
 
+    while (true) {
 #ifdef PIPE_TIMING
-    unsigned long long tm_dma = 0, tm_bar = 0, tm_per = 0, tm_last = 0, tm_start;
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_start) :: "memory");
+        unsigned long long tm_t0;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_t0) :: "memory");
 #endif
-    bf16x8_t xa[PFX], ya[PFY], xb[PFX], yb[PFY];
-    load_frags(0, 0, xa, ya);
-    load_frags(0, 1, xb, yb);
-    for (int kt = 0; kt + 1 < nk; ++kt) {
-        const int stage = kt & 1;
-        PIPE_SB();
-        if (PIPE_SCHED == 2) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) dma_q(q, stage ^ 1);
+        for (int i = 0; i < PFX; ++i)
+#pragma unroll
+            for (int j = 0; j < PFY; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        bf16x8_t xa[PFX], ya[PFY], xb[PFX], yb[PFY];
+        load_frags(st, 0, xa, ya);
+        load_frags(st, 1, xb, yb);
+        for (int kt = 0; kt + 1 < nk; ++kt) {
             PIPE_SB();
+            mma_dma(xa, ya, st ^ 1);
+            dma_next();
+            PIPE_SB();
+            load_frags(st, 2, xa, ya);
+            PIPE_SB();
+            mma(xb, yb);
+            PIPE_SB();
+            load_frags(st, 3, xb, yb);
+            PIPE_SB();
+            mma(xa, ya);
+            PIPE_SB();
+#ifdef PIPE_TIMING   // s_memtime stamps around the barrier: own-DMA wait and barrier wait per K-step
+            unsigned long long t1, t2, t3;
+            asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
+            asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
+#endif
+            __syncthreads();   // vmcnt(0): this wave's pieces of K-step kt + 1 have landed; lgkmcnt(0): its reads of stage st are done
+#ifdef PIPE_TIMING
+            asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t3) :: "memory");
+            tm_dma += t2 - t1; tm_bar += t3 - t2; ++tm_ksteps;
+#endif
+            st ^= 1;
+            load_frags(st, 0, xa, ya);
+            PIPE_SB();
+            mma(xb, yb);   // (the last k-substep of K-step kt runs after the barrier and covers the first reads of the new stage)
+            PIPE_SB();
+            load_frags(st, 1, xb, yb);
         }
-        mma_dma(xa, ya, 0, PIPE_SCHED == 0 ? 5 : PIPE_SCHED == 1 ? 9 : 0, stage ^ 1);
-        PIPE_SB();
-        load_frags(stage, 2, xa, ya);
-        PIPE_SB();
-        mma_dma(xb, yb, 5, PIPE_SCHED == 0 ? 4 : 0, stage ^ 1);
-        dma_next();
-        PIPE_SB();
-        load_frags(stage, 3, xb, yb);
+        // last K-step: nothing of this tile left to stage
         PIPE_SB();
         mma(xa, ya);
         PIPE_SB();
-#ifdef PIPE_TIMING   // s_memtime stamps around the barrier (tools/gemm_pipe_probe.py --timing): barrier wait, own DMA wait and the K-step period
-        unsigned long long t1, t2, t3;
-        asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
-        asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
-#endif
-        __syncthreads();   // vmcnt(0): this wave's pieces of tile kt + 1 have landed; lgkmcnt(0): its reads of stage kt are done
+        load_frags(st, 2, xa, ya);
+        PIPE_SB();
+        mma(xb, yb);
+        PIPE_SB();
+        load_frags(st, 3, xb, yb);
+        PIPE_SB();
+        mma(xa, ya);
+        PIPE_SB();
+        mma(xb, yb);
+        PIPE_SB();
 #ifdef PIPE_TIMING
-        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t3) :: "memory");
-        tm_dma += t2 - t1; tm_bar += t3 - t2; if (kt > 0) tm_per += t1 - tm_last; tm_last = t1;
+        unsigned long long tm_t1;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_t1) :: "memory");
+        tm_loop += tm_t1 - tm_t0;
 #endif
-        load_frags(stage ^ 1, 0, xa, ya);
-        PIPE_SB();
-        mma(xb, yb);
-        PIPE_SB();
-        load_frags(stage ^ 1, 1, xb, yb);
-    }
-    {   // last K-step: nothing left to stage
-        const int stage = (nk - 1) & 1;
-        PIPE_SB();
-        mma(xa, ya);
-        PIPE_SB();
-        load_frags(stage, 2, xa, ya);
-        PIPE_SB();
-        mma(xb, yb);
-        PIPE_SB();
-        load_frags(stage, 3, xb, yb);
-        PIPE_SB();
-        mma(xa, ya);
-        PIPE_SB();
-        mma(xb, yb);
-    }
 
+        // the NEXT tile's first K-step goes out before this tile's epilogue: stage st ^ 1 has been free since the last barrier, and the address
+        // state of this tile is dead (the epilogue works from m0 / n0 / eplan)
+        const int nbid = bid + (int)gridDim.x;
+        const bool more = WALK && nbid < ntiles;
+        int ntm = 0, ntn = 0;
+        if (more) {
+            tile_of(nbid, ntm, ntn);
+            setup(ntm * PBM, ntn * PBN);
+            kb = 0; tap = 0; c0b = 0;
+#pragma unroll
+            for (int q = 0; q < PWP + PAP; ++q) dma_q(q, st ^ 1);
+            dma_next();
+        }
+        PIPE_SB();
+
+        // the epilogue's lane-derived state is formed from an OPAQUE copy of the thread index: derived from `tid` it is hoisted out of the
+        // tile loop, lives across the K-loop next to 216 accumulator / fragment registers and is spilled (its reloads then queue behind the
+        // pieces just issued)
+        int te = tid;
+        asm volatile("" : "+v"(te));
+        const int e_wave = te >> 6, e_l31 = te & 31, e_lh = (te >> 5) & 1;
+        const int e_wm = e_wave >> 1, e_wn = e_wave & 1;
+        const float2* const lnp = p.ln_stats != nullptr ? lnrow : nullptr;
+        if constexpr (EPI == EPI_GEGLU) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, lnp, epi_vec);
+        else gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0);
 #ifdef PIPE_TIMING
-    unsigned long long tm_loop_end;
-    asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_loop_end) :: "memory");
+        unsigned long long tm_t2;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_t2) :: "memory");
+        tm_epi += tm_t2 - tm_t1;
 #endif
-    const float2* const lnp = p.ln_stats != nullptr ? lnrow : nullptr;
-    if constexpr (EPI == EPI_GEGLU) {
-        if (eplan.fast) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, wm, wn, l31, lh, lnp, epi_vec);
-        else gemm_epilogue<EPI_GEGLU, false, PFX, PFY, 2, 5>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, lnp);
-    } else {
-        if (eplan.fast) gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, lnp, epi_vec, eplan.img0);
-        else gemm_epilogue<EPI_LINEAR, false, PFX, PFY, 2, 5>(p, acc, m0, n0, wm, wn, l31, lh, tn * 2 + wn, lnp);
+        if (!more) break;
+        __syncthreads();   // every wave is done with this tile's vectors / row statistics
+        bid = nbid; tm = ntm; tn = ntn;
+        m0 = tm * PBM; n0 = tn * PBN;
+        eplan = plan_of(m0);
+        stage_tile_vectors(m0, n0, eplan);
+        __syncthreads();   // + vmcnt(0): the next tile's first K-step has landed
+        st ^= 1;
     }
 #ifdef PIPE_TIMING
-    if (blockIdx.x == 8 && lane == 0 && p.splitk_ws) {   // per wave: [DMA wait, barrier wait, K-step period sum, K-steps - 1, prologue, loop, epilogue]
+    if (blockIdx.x == 8 && lane == 0 && p.splitk_ws) {   // per wave: [own-DMA wait, barrier wait, K-steps timed, K-loops, epilogues (+ next tile's setup), kernel] in s_memtime ticks
         unsigned long long tm_end;
         asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_end) :: "memory");
         float* o = (float*)p.splitk_ws + wave * 8;
-        o[0] = (float)tm_dma; o[1] = (float)tm_bar; o[2] = (float)tm_per; o[3] = (float)(nk - 2); o[4] = (float)(tm_start - tm_k0); o[5] = (float)(tm_loop_end - tm_start); o[6] = (float)(tm_end - tm_loop_end);
+        o[0] = (float)tm_dma; o[1] = (float)tm_bar; o[2] = (float)tm_ksteps; o[3] = (float)tm_loop; o[4] = (float)tm_epi; o[5] = (float)(tm_end - tm_k0);
     }
 #endif
 }
@@ -313,10 +351,16 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
 template <int AMODE, int EPI>
 int pipe_launch(const VkGemmDesc* d, hipStream_t stream) {
     const int tilesN = d->N / PBN, tilesM = (d->M + PBM - 1) / PBM;
+    const int ntiles = tilesM * tilesN;
+    // GEGLU: 256 resident workgroups (one per CU: 162 KB of LDS) walk the tile list, +1-9 % over one workgroup per tile. LINEAR: one workgroup
+    // per tile -- a workgroup that ends does not wait for its stores, so the next one's first pieces fly while they drain, whereas the tile
+    // walk's first barrier (vmcnt(0)) of the next tile waits for every store of the last: measured -7..-10 % on the short-K level-0 / level-1
+    // shapes, +-1 % on the deep-K ones (same-box sweep, profiles/r04_gemm_pipe.txt)
+    const int grid = (EPI == EPI_GEGLU && ntiles > 256) ? 256 : ntiles;
     VkGemmDesc desc = *d;
     const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally
-    if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, AMODE == AMODE_DENSE>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
-    else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false>), dim3(tilesM * tilesN), dim3(PNT), 0, stream, desc);
+    if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, AMODE == AMODE_DENSE>), dim3(grid), dim3(PNT), 0, stream, desc);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false>), dim3(grid), dim3(PNT), 0, stream, desc);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
@@ -327,6 +371,7 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream) {
 extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d) {
     if ((d->epi != EPI_LINEAR && d->epi != EPI_GEGLU) || d->out_f32 || (d->N % PBN) != 0 || d->mx8_out || d->A2) return 0;
     if (d->epi == EPI_GEGLU && d->amode != AMODE_DENSE) return 0;
+    if (!epi_fast_everywhere(*d, d->epi, PBM)) return 0;   // the kernel carries the LDS-staged epilogues only
     if ((unsigned long long)PBN * d->K * 2ull >= P_LIMIT) return 0;
     if (d->amode == AMODE_DENSE) return ((unsigned long long)PBM * d->lda * 2ull < P_LIMIT) ? 1 : 0;
     if (d->amode == AMODE_CONV3X3) {
