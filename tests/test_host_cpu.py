@@ -412,6 +412,32 @@ def test_config_fallback_equals_shipped_yaml_and_import_is_lazy():
         cfg._UNET_KWARGS = saved
 
 
+def test_rowstat_parts_answer_matches_the_launch_that_follows():
+    """vk_gemm_rowstat_parts is asked BEFORE the caller can set rowstat_out (the buffer is sized from the answer): it must describe the launch
+    with the pointer set. Round 4 regression: the streaming K = 320 kernel, which is not chosen for row-sum emitting launches, answered the
+    query (1 slab) and the tiled kernel then wrote its 2 slabs into a buffer of one."""
+    import ctypes as C
+    from vista_amd import _lib, ops
+    lib = _lib.load()
+    one = C.c_void_p(4096)
+    slabs = {1: (128, 2), 2: (128, 4), 3: (256, 4), 4: (320, 2), 5: (160, 1), 7: (320, 2)}   # tile variant -> (tile width, wave columns)
+    for M, N, K in ((50 * 9216, 320, 320), (50 * 9216, 320, 1280), (50 * 2304, 640, 640), (50 * 576, 1280, 1280), (7 * 9216, 320, 320), (1440, 320, 320)):
+        for res in (False, True):
+            d = _lib.VkGemmDesc()
+            d.A = d.Wt = d.out = one
+            d.M, d.N, d.K, d.lda, d.ldc, d.alpha = M, N, K, K, N, 1.0
+            d.amode, d.epi = ops.AMODE_DENSE, ops.EPI_LINEAR
+            d.splitk_ws, d.splitk_ws_bytes = one, 160 << 20
+            if res:
+                d.res1, d.ld_res1 = one, N
+            parts = lib.vk_gemm_rowstat_parts(C.byref(d))      # as ops._gemm asks: pointer not set yet
+            d.rowstat_out = one
+            cfg, ks = divmod(lib.vk_gemm_tile_choice(C.byref(d)), 16)
+            assert ks in (1, 2) and cfg in slabs, (M, N, K, res, cfg, ks)
+            bn, wn = slabs[cfg]
+            assert parts == (N + bn - 1) // bn * wn, (M, N, K, res, cfg, parts)
+
+
 def test_gemm_launch_rules_are_pinned():
     """vk_gemm_tile_choice: the launcher's (block tile, K slices) for the BASELINE shapes and for one rank of an 8-GPU run, as host arithmetic
     (no GPU). Pins what the same-box sweeps of rounds 1-3 chose (profiles/r03_tile5_sweep.txt, r03_gemm_sweep_rank7*.jsonl,

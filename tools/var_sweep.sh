@@ -5,7 +5,7 @@ mkdir -p gpurun_out/var
 for r in 1 2; do
   for v in cur "$@"; do
     if [ $v = cur ]; then unset VISTA_HIP_LIB; else export VISTA_HIP_LIB=$PWD/gpurun_var_$v.so; fi
-    PROBE_FAST=1 python tools/gemm_pipe_probe.py > gpurun_out/var/${v}_$r.txt 2>&1
+    PROBE_FAST=3 python tools/gemm_pipe_probe.py > gpurun_out/var/${v}_$r.txt 2>&1
   done
 done
 unset VISTA_HIP_LIB

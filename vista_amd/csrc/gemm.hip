@@ -581,10 +581,11 @@ extern "C" int vk_gemm_rowstat_parts(const VkGemmDesc* d) {
     const int rc = validate(d);
     if (rc != VK_OK) return rc;
     if (d->epi != EPI_LINEAR || d->out_f32) return VK_EINVAL;
-    if (const int fit = stream_fit(d)) return d->N / (32 * fit);  // one slab per column tile: the workgroup combines its waves' row sums
     VkGemmDesc q = *d;
+    q.rowstat_out = (float*)1;  // what the launcher will see (callers size the buffer from this answer BEFORE they can set the pointer): the
+                                // streaming kernel is not chosen on its own for a row-sum emitting launch, and such a launch is never split-K
+    if (const int fit = stream_fit(&q)) return d->N / (32 * fit);  // one slab per column tile: the workgroup combines its waves' row sums
     if ((q.tile_cfg & 7) == 6) q.tile_cfg &= ~7;
-    q.rowstat_out = (float*)1;  // what the launcher will see: never split-K
     const TileChoice t = choose_tile(&q);
     int bn, wn;
     tile_geometry(t.cfg, bn, wn);
