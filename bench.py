@@ -59,7 +59,7 @@ def cpu_baseline(net, T, H, W, seed):
     (T frames) of the CFG pair each, at the full 72x128 latent:
       (a) the first level-0 SpatialVideoTransformer (input_blocks.1.1: width 320, 9216 tokens per frame: spatial + temporal transformer block),
       (b) the first level-0 VideoResBlock (input_blocks.1.0: 2-D ResBlock + 3x1x1 temporal ResBlock + blend).
-    Their FLOPs are counted by torch's flop counter. The level-0 transformers and ResBlocks are ~60 % of the step's FLOPs; the whole step is
+    Their FLOPs are counted by torch's flop counter. The ten level-0 (transformer, ResBlock) pairs of a step are ~39 % of its FLOPs (`share_of_step_flop` in the output); the whole step is
     estimated as (step FLOPs) / (blended rate of the two pieces). Nothing is read from earlier rounds' files. Also returns the HIP path's
     relative L2 error against the oracle on both pieces (the same modules of the timed network, same inputs)."""
     from torch.utils.flop_counter import FlopCounterMode
@@ -356,13 +356,13 @@ def main():
         avg_ms = sum(l0) / len(l0)
         flop = 4.0 * nbh * float(H * W) ** 2 * 64
         ach = flop / (avg_ms * 1e-3) / 1e12
-        traffic = None  # HBM bytes per launch from the separate PMC passes (profiles/r03_attn_traffic.json), full config only
-        tp = os.path.join(ROOT, "profiles", "r03_attn_traffic.json")
+        traffic = None  # HBM bytes per launch from the separate PMC passes (profiles/r04_attn_traffic.json), full config only
+        tp = os.path.join(ROOT, "profiles", "r04_attn_traffic.json")
         if full and world == 1 and os.path.exists(tp):
             traffic = json.load(open(tp))["traffic_bytes_per_launch"]
         roofline = {"kernel": "attn_spatial_kernel (level-0 spatial self-attention)", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": traffic,
-                    "traffic_source": "rocprofv3 PMC passes of the same kernel and shape, profiles/r03_attn_traffic.json (PMC passes cannot share a run with the timed region)",
+                    "traffic_source": "rocprofv3 PMC passes of the same kernel and shape, profiles/r04_attn_traffic.json (PMC passes cannot share a run with the timed region)",
                     "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop}
 
     def layout(sh):

@@ -1,7 +1,7 @@
 # Round-4 measurement set in ONE gpurun call: default bench line, rocprofv3 kernel trace of the bench, per-step kernel table, SQ counters of the
 # fused FeedForward / level-0 GEMM family, HBM traffic of the level-0 attention and the fused FeedForward.   usage (GPU box): bash tools/prof_r04.sh
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04
+O=$R/gpurun_out/r04d
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log > $O/r04_bench_default.json
@@ -16,7 +16,7 @@ for kind in ffused conv ffout linear; do
     rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_g -o p -- python $R/tools/one_kernel.py $kind 0 > /tmp/pmc_g.log 2>&1
     db=$(find /tmp/pmc_g -name '*.db' | head -1)
     echo "== $kind level 0, counters: $set" >> $O/r04_pmc_gemm_sq.txt
-    python $R/tools/pmc_summary.py "$db" "$( [ $kind = ffused ] && echo ff_fused_kernel || ( [ $kind = linear ] && echo gemm_stream_kernel || echo gemm_kernel ) )" 2>&1 | grep -v "^cols" >> $O/r04_pmc_gemm_sq.txt
+    python $R/tools/pmc_summary.py "$db" "$( [ $kind = ffused ] && echo ff_fused_kernel || ( [ $kind = linear ] && echo gemm_stream_kernel || echo gemm_pipe_kernel ) )" 2>&1 | grep -v "^cols" >> $O/r04_pmc_gemm_sq.txt
   done
 done
 for kind in attn ffused; do
