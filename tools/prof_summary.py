@@ -8,6 +8,12 @@ import sys
 
 
 def short(name):
+    if "gemm_pipe_kernel" in name:   # <AMODE, EPI, NT_A>: the eight-wave pipelined 256x320 kernel (round 4)
+        m = re.search(r"gemm_pipe_kernel<([^>]*)>", name)
+        a = [x.strip() for x in m.group(1).split(",")] if m else ["?", "?"]
+        am = {"0": "dense", "1": "conv3x3", "2": "temporal3"}.get(a[0], a[0])
+        ep = {"0": "linear", "1": "geglu"}.get(a[1], a[1])
+        return f"gemm_pipe_kernel[{am},{ep},bf16,256x320 pipelined]"
     if "gemm_kernel" in name:
         m = re.search(r"gemm_kernel<([^>]*)>", name)
         a = [x.strip() for x in m.group(1).split(",")]
