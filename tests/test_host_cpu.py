@@ -485,5 +485,5 @@ def test_gemm_launch_rules_are_pinned():
     assert choice(r2, 1280, 5120, stats=True) == (5, 1)
     assert choice(r2, 10240, 1280, epi=ops.EPI_GEGLU) == (7, 1)  # 512 tiles of 256x320 = 2 rounds instead of 640 = 3
     cfg, ks = choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32)
-    assert cfg == 4 and ks >= 2, "small-M deep-K convolutions run split-K on the big tile"
+    assert cfg == 7 and ks >= 2, "small-M deep-K convolutions run split-K on the big tile (its pipelined kernel since round 4)"
     assert choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32, ws=False) [1] == 1  # no workspace, no split

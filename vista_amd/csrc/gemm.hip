@@ -37,7 +37,7 @@
 
 // gemm_pipe.hip: the eight-wave pipelined 256x320 variant (tile_cfg 7); fit = 1 when it takes the problem
 extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d);
-extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream);
+extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream, int ksplit);
 
 namespace {
 
@@ -507,7 +507,7 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     // 256x320 chosen by the rules above (not forced): the eight-wave pipelined kernel where it takes the problem (gemm_pipe.hip; same-box
     // sweep +14-17 % on the 3x3 convs, +5-15 % on the dense / temporal shapes, bitwise the same results). VISTA_GEMM_PIPE=0: A/B hook.
     static const bool pipe_on = [] { const char* e = getenv("VISTA_GEMM_PIPE"); return !e || atoi(e) != 0; }();
-    if (cfg == 4 && ksplit == 1 && force == 0 && pipe_on && vk_gemm_pipe_fit(d)) cfg = 7;
+    if (cfg == 4 && force == 0 && pipe_on && !d->out_f32 && vk_gemm_pipe_fit(d)) cfg = 7;   // (also the split-K launches of the rule above)
     // GEGLU: +10-11 % at level 1 and +16-17 % at level 2 over the better of 256x256 / 256x320 (sixteen waves), also on one rank's small
     // problems; K = 320 (level 0 without the fused FeedForward) stays on the persistent 256x256 kernel, where the pipelined one is 5 % behind
     if (epi == EPI_GEGLU && (cfg == 3 || cfg == 4) && force == 0 && pipe_on && d->K >= 640 && vk_gemm_pipe_fit(d)) cfg = 7;
@@ -533,7 +533,15 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
     if constexpr (AMODE != AMODE_CONV3D) {
         // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
         // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
-        if (t.cfg == 7) return vk_gemm_pipe_launch(d, stream);   // eight 64x160 wave tiles, pipelined K-step (gemm_pipe.hip)
+        if (t.cfg == 7) {   // eight 64x160 wave tiles, pipelined K-step (gemm_pipe.hip)
+            const int rc = vk_gemm_pipe_launch(d, stream, t.ksplit);
+            if (rc != VK_OK || t.ksplit == 1) return rc;
+            const long long quads = (long long)d->M * (d->N >> 2);   // the split-K finishing pass, as launch_cfg's
+            const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);
+            hipLaunchKernelGGL((splitk_finish_kernel<OUT_F32>), dim3(grid), dim3(256), 0, stream, *d, t.ksplit);
+            VK_CHECK_LAUNCH();
+            return VK_OK;
+        }
         if (t.cfg == 4) return launch_cfg<AMODE, EPI, OUT_F32, 8, 2, 1, 5>(d, stream, t.ksplit);
     }
     // 256x256 runs as SIXTEEN waves (4 per SIMD, 64x64 wave tiles, <= 128 VGPRs): same bytes per FLOP as the 8-wave layout, but twice

@@ -36,8 +36,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int AMODE, int EPI, bool NT_A>
-__global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
+template <int AMODE, int EPI, bool NT_A, bool SPLIT>
+__global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, const int ksplit) {
     constexpr int LN_OFF = 2 * PSTAGE, EV_OFF = LN_OFF + PBM * 8;
     constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
     constexpr bool WALK = (EPI == EPI_GEGLU);   // persistent tile walk (pipe_launch); the LINEAR instantiations are compiled as one tile per workgroup
@@ -57,8 +57,12 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     // tile order: as gemm.hip (column tile fastest unless the weights overflow the L2, then panels of 8 row tiles). The launch is
     // PERSISTENT: workgroup b walks tiles b, b + gridDim.x, ... (gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so a
     // workgroup's tiles stay in its XCD's range of the remap)
+    // SPLIT (small-M, deep-K LINEAR problems, as gemm.hip's split-K): workgroup = (K slice, tile), the K slice as the slow index; a slice's
+    // fp32 partial tile goes to the workspace [slice][M][N] and gemm.hip's finishing pass applies the epilogue
+    int kslice = 0;
     auto tile_of = [&](const int bid, int& tm, int& tn) __attribute__((always_inline)) {
-        const int logical = xcd_remap(bid, ntiles);
+        int logical = xcd_remap(bid, SPLIT ? ntiles * ksplit : ntiles);
+        if (SPLIT) { kslice = logical / ntiles; logical -= kslice * ntiles; }
         if (tilesN < 8 || (long long)p.N * p.K * 2 <= (3LL << 20)) {
             tn = logical % tilesN;
             tm = logical / tilesN;
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
         }
     };
 
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    int nk = nk_all;        // K-steps of this workgroup (SPLIT: of its slice, set below)
     int tap = 0, c0b = 0;   // (tap, channel-slab byte offset) of the NEXT K-step to stage (conv loaders: K-step = (slab kt / NTAPS, tap kt % NTAPS))
     int kb = 0;             // its byte offset inside a weight row (dense: also inside an activation row)
 
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     auto stage_tile_vectors = [&](const int m0, const int n0, const EpiPlan& e) __attribute__((always_inline)) {
         int tv = tid;
         asm volatile("" : "+v"(tv));   // (as the epilogue: nothing lane-derived of this pass is to live across the K-loop)
+        if (SPLIT) return;   // (the finishing pass applies the epilogue)
         epi_stage_vectors<PBN, PNT>(p, epi_vec, n0, e, tv);
         if (p.ln_stats != nullptr) {
             for (int r = tv; r < PBM; r += PNT) {
@@ -227,6 +233,12 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
     tile_of(bid, tm, tn);
     int m0 = tm * PBM, n0 = tn * PBN;
     setup(m0, n0);
+    if (SPLIT) {
+        const int kt0 = (int)((long long)kslice * nk_all / ksplit), kt1 = (int)((long long)(kslice + 1) * nk_all / ksplit);
+        nk = kt1 - kt0;
+        kb = kt0 * BK * 2;
+        if (AMODE != AMODE_DENSE) { tap = kt0 % NTAPS; c0b = (kt0 / NTAPS) * BK * 2; }
+    }
     int st = 0;   // stage holding the current K-step
 #pragma unroll
     for (int q = 0; q < PWP + PAP; ++q) dma_q(q, 0);
@@ -322,7 +334,15 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
         const int e_wave = te >> 6, e_l31 = te & 31, e_lh = (te >> 5) & 1;
         const int e_wm = e_wave >> 1, e_wn = e_wave & 1;
         const float2* const lnp = p.ln_stats != nullptr ? lnrow : nullptr;
-        if constexpr (EPI == EPI_GEGLU) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, lnp, epi_vec);
+        if constexpr (SPLIT) {   // fp32 partial tile of this K slice (gemm.hip: gemm_kernel's split-K branch)
+            VkGemmDesc q = p;
+            q.out = (float*)p.splitk_ws + (size_t)kslice * p.M * p.N;
+            q.ldc = p.N;
+            q.bias = nullptr; q.rowvec = nullptr; q.res1 = nullptr; q.res2 = nullptr;
+            q.alpha = 1.f; q.beta = 0.f;
+            q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr; q.act = 0;
+            gemm_epilogue<EPI_LINEAR, true, PFX, PFY, 2, 5>(q, acc, m0, n0, e_wm, e_wn, e_l31, e_lh);
+        } else if constexpr (EPI == EPI_GEGLU) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, lnp, epi_vec);
         else gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0);
 #ifdef PIPE_TIMING
         unsigned long long tm_t2;
@@ -349,18 +369,27 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p) {
 }
 
 template <int AMODE, int EPI>
-int pipe_launch(const VkGemmDesc* d, hipStream_t stream) {
+int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
     const int tilesN = d->N / PBN, tilesM = (d->M + PBM - 1) / PBM;
     const int ntiles = tilesM * tilesN;
+    VkGemmDesc desc = *d;
+    const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally
+    if constexpr (EPI == EPI_LINEAR) {
+        if (ksplit > 1) {   // K slices x tiles; the caller (gemm.hip) runs the finishing pass
+            if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, AMODE == AMODE_DENSE, true>), dim3(ntiles * ksplit), dim3(PNT), 0, stream, desc, ksplit);
+            else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false, true>), dim3(ntiles * ksplit), dim3(PNT), 0, stream, desc, ksplit);
+            VK_CHECK_LAUNCH();
+            return VK_OK;
+        }
+    }
+    if (ksplit > 1) return VK_EINVAL;
     // GEGLU: 256 resident workgroups (one per CU: 162 KB of LDS) walk the tile list, +1-9 % over one workgroup per tile. LINEAR: one workgroup
     // per tile -- a workgroup that ends does not wait for its stores, so the next one's first pieces fly while they drain, whereas the tile
     // walk's first barrier (vmcnt(0)) of the next tile waits for every store of the last: measured -7..-10 % on the short-K level-0 / level-1
     // shapes, +-1 % on the deep-K ones (same-box sweep, profiles/r04_gemm_pipe.txt)
     const int grid = (EPI == EPI_GEGLU && ntiles > 256) ? 256 : ntiles;
-    VkGemmDesc desc = *d;
-    const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally
-    if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, AMODE == AMODE_DENSE>), dim3(grid), dim3(PNT), 0, stream, desc);
-    else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false>), dim3(grid), dim3(PNT), 0, stream, desc);
+    if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, AMODE == AMODE_DENSE, false>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
+    else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false, false>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
@@ -387,16 +416,17 @@ extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d) {
     return 0;
 }
 
-extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream_) {
+extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream_, int ksplit) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!vk_gemm_pipe_fit(d)) return VK_EINVAL;
+    if (ksplit > 1 && (d->epi != EPI_LINEAR || !d->splitk_ws || d->ln_stats || d->rowstat_out || d->act)) return VK_EINVAL;
 #ifndef VK_PIPE_ONLY   // (-DVK_PIPE_ONLY=<amode>: a one-loader build for tuning sessions)
 #define VK_PIPE_ONLY -1
 #endif
     constexpr int only = VK_PIPE_ONLY;
     if constexpr (only < 0 || only == AMODE_DENSE) if (d->amode == AMODE_DENSE)
-        return d->epi == EPI_GEGLU ? pipe_launch<AMODE_DENSE, EPI_GEGLU>(d, stream) : pipe_launch<AMODE_DENSE, EPI_LINEAR>(d, stream);
-    if constexpr (only < 0 || only == AMODE_CONV3X3) if (d->amode == AMODE_CONV3X3) return pipe_launch<AMODE_CONV3X3, EPI_LINEAR>(d, stream);
-    if constexpr (only < 0 || only == AMODE_TEMPORAL3) if (d->amode == AMODE_TEMPORAL3) return pipe_launch<AMODE_TEMPORAL3, EPI_LINEAR>(d, stream);
+        return d->epi == EPI_GEGLU ? pipe_launch<AMODE_DENSE, EPI_GEGLU>(d, stream, ksplit) : pipe_launch<AMODE_DENSE, EPI_LINEAR>(d, stream, ksplit);
+    if constexpr (only < 0 || only == AMODE_CONV3X3) if (d->amode == AMODE_CONV3X3) return pipe_launch<AMODE_CONV3X3, EPI_LINEAR>(d, stream, ksplit);
+    if constexpr (only < 0 || only == AMODE_TEMPORAL3) if (d->amode == AMODE_TEMPORAL3) return pipe_launch<AMODE_TEMPORAL3, EPI_LINEAR>(d, stream, ksplit);
     return VK_EINVAL;
 }
