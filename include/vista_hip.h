@@ -35,8 +35,11 @@ typedef struct VkGemmDesc {
     int32_t H, Wd, Cin, Hout, Wout, stride, ups; /* CONV3X3: source H x Wd (before the x`ups` nearest upsample)   */
     int32_t T, S;        /* TEMPORAL3: frames per clip, tokens per frame. EPI_TRANS: S = tokens per image.
                             CONV3D (3x3x3, pad 1 over [frames][H][Wd][Cin], K = 27*Cin): T = frames per clip        */
-    int32_t tile_cfg;    /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 block tile (tests / tuning). Weight rows
-                            are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                                                      */
+    int32_t tile_cfg;    /* 0 = auto; forced variants (tests / tuning): 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (sixteen waves),
+                            5 = 128x160 (two workgroups per CU; DENSE LINEAR), 6 = the weight-stationary streaming kernel (K = 320, N = 320 / 640 /
+                            960), 7 = 256x320 eight-wave pipelined kernel (DENSE / CONV3X3 without upsample / TEMPORAL3 without halos x LINEAR,
+                            DENSE x GEGLU; bitwise equal to 4). A variant that does not take the problem falls back to the launcher's choice.
+                            Weight rows are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                          */
     const void* halo_prev; /* TEMPORAL3, frame-sharded runs: bf16 [clips][S][Cin] frame preceding / following the local frame range   */
     const void* halo_next; /* (from the neighbour rank); NULL = the conv's zero padding at the window ends                               */
     void* splitk_ws;     /* optional fp32 workspace for split-K of small-M, deep-K LINEAR problems (NULL = never split); must not be  */
