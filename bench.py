@@ -170,9 +170,9 @@ def gemm_rooflines(ops, n_img, H, W):
          2.0 * M * 8 * C * C, M * C * 2 + M * 4 * C * 2, "mfma"),
         ("ff_fused_kernel level-0 FeedForward 460800x320->1280(GEGLU)->320 (+residual), hidden activation never written", lambda: ops.ff_fused(x, pw_geglu, pw_ffo, res1=res),
          2.0 * M * 8 * C * C + 2.0 * M * 4 * C * C, 3.0 * M * C * 2, "mfma"),
-        ("the same FeedForward as two launches (GEGLU GEMM + out-projection GEMM: the round-3 path)", lambda: ops.linear(ops.linear(x, pw_geglu), pw_ffo_plain, res1=res),
+        ("the same FeedForward as two launches (GEGLU GEMM + out-projection GEMM: the round-3 path, out-projection on the pipelined kernel)", lambda: ops.linear(ops.linear(x, pw_geglu), pw_ffo_plain, res1=res),
          2.0 * M * 8 * C * C + 2.0 * M * 4 * C * C, 3.0 * M * C * 2 + 2.0 * M * 4 * C * 2, "mfma"),
-        ("gemm_kernel[conv3x3,linear,256x320] level-0 conv 320->320 @72x128", lambda: ops.conv3x3(x3, pw_conv, n_img, H, W),
+        ("gemm_pipe_kernel[conv3x3,linear,256x320 pipelined] level-0 conv 320->320 @72x128", lambda: ops.conv3x3(x3, pw_conv, n_img, H, W),
          2.0 * M * C * 9 * C, 2.0 * M * C * 2, "mfma"),
     ]
     out = []
