@@ -440,9 +440,10 @@ def test_sampler_elementwise():
 
 
 # ------------------------------------------------------------------------------------------------ block-tile variants
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 7])
 def test_gemm_family_all_tile_configs(cfg):
-    """Every block-tile variant (128x128, 256x128, 256x256, 256x320) of every loader / epilogue, on shapes with ragged M and N edges."""
+    """Every block-tile variant (128x128, 256x128, 256x256, 256x320 sixteen-wave, 128x160, 256x320 eight-wave pipelined) of every loader /
+    epilogue, on shapes with ragged M and N edges (a forced variant that does not take a problem falls back to the launcher's choice)."""
     ops = _ops()
     ops.TILE_CFG = cfg
     try:
@@ -557,6 +558,125 @@ def test_splitk_conv3x3_and_temporal_conv():
     close(pt, reft, "plain temporal conv")
 
 
+# ------------------------------------------------------------------------------------------------ round 4: the pipelined 256x320 kernel
+@pytest.mark.parametrize("kind", ["dense+res+stats", "qkv_lnfold", "ff_out+blend", "geglu_lnfold", "conv3x3+emb+res", "conv3x3_stride2", "conv3x3_asym",
+                                  "conv_t3", "conv_t3+blend"])
+@pytest.mark.parametrize("n,H,W,C", [(3, 20, 24, 320), (5, 9, 13, 640), (9, 36, 64, 320)])   # ragged last tile, tiles spanning 3-4 images, > 256 tiles
+def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
+    """gemm_pipe.hip (VkGemmDesc.tile_cfg = 7: eight waves, 64x160 wave tiles, fragments double-buffered across the K-step barrier, the next
+    K-step's LDS-DMA pieces issued between the MFMAs as buffer loads whose out-of-range offsets are the conv padding / the rows past M) against the
+    sixteen-wave 256x320 kernel (tile_cfg 4), bit for bit, for every loader x epilogue it takes -- and against torch fp32. Reference call sites:
+    openaimodel.py:198,232 (ResBlock convs), :136 (Downsample), model.py:77-81 (asymmetric pad), video_model.py:38-52 (time_stack),
+    attention.py:85-110 (GEGLU / FeedForward), :344-346,421 (projections)."""
+    ops = _ops()
+    S = H * W
+    M = n * S
+    x = rnd(M, C)
+    x3 = x.view(n, S, C)
+    res = rnd(M, C, seed=3)
+    rv = rnd(n, C, seed=5).float()
+    ref = None
+    if kind == "dense+res+stats":
+        w, b = rnd(C, C, scale=C ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda: ops.linear(x, pw, res1=res, rowvec=rv, rows_per_vec=S, emit_stats=True)  # noqa: E731
+        ref = x.float() @ w.float().t() + b + res.float() + rv.repeat_interleave(S, 0)
+    elif kind == "qkv_lnfold":
+        nrm = _Norm(C, 7)
+        w, b = rnd(3 * C, C, scale=C ** -0.5, seed=1), rnd(3 * C, seed=2).float()
+        pw = ops.pack_linear(w, b, ln=nrm)
+        st = ops.rowstats(x)
+        fn = lambda: ops.linear(x, pw, ln=st)  # noqa: E731
+        ref = _ln_ref(x, nrm.weight, nrm.bias) @ w.float().t() + b
+    elif kind == "ff_out+blend":
+        h4 = rnd(M, 4 * C, seed=9)
+        w, b = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda: ops.linear(h4, pw, res1=res, alpha=0.4, res2=x, rowvec2=rv, beta=0.6, rows_per_vec=S)  # noqa: E731
+        ref = 0.4 * (h4.float() @ w.float().t() + b + res.float()) + 0.6 * (x.float() + rv.repeat_interleave(S, 0))
+    elif kind == "geglu_lnfold":
+        nrm = _Norm(C, 7)
+        w, b = rnd(8 * C, C, scale=C ** -0.5, seed=1), rnd(8 * C, seed=2).float()
+        pw = ops.pack_geglu(w, b, ln=nrm)
+        st = ops.rowstats(x)
+        fn = lambda: ops.linear(x, pw, ln=st)  # noqa: E731
+        a, g = (_ln_ref(x, nrm.weight, nrm.bias) @ w.float().t() + b).chunk(2, dim=-1)
+        ref = a * F.gelu(g)
+    elif kind.startswith("conv3x3"):
+        w, b = rnd(C, C, 3, 3, scale=(9 * C) ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_conv3x3(w, b)
+        xn = _tok2nchw(x3, n, H, W)
+        if kind == "conv3x3+emb+res":
+            fn = lambda: ops.conv3x3(x3, pw, n, H, W, rowvec=rv, res1=x3)[0]  # noqa: E731
+            ref = _nchw2tok(F.conv2d(xn, w.float(), b, padding=1)) + rv[:, None, :] + x3.float()
+        elif kind == "conv3x3_stride2":
+            if H % 2 or W % 2:
+                pytest.skip("stride 2 needs even H, W")
+            fn = lambda: ops.conv3x3(x3, pw, n, H, W, stride=2)[0]  # noqa: E731
+            ref = _nchw2tok(F.conv2d(xn, w.float(), b, stride=2, padding=1))
+        else:
+            if H % 2 or W % 2:
+                pytest.skip("the asymmetric-pad Downsample needs even H, W")
+            fn = lambda: ops.conv3x3(x3, pw, n, H, W, stride=2, asym_pad=True)[0]  # noqa: E731
+            ref = _nchw2tok(F.conv2d(F.pad(xn, (0, 1, 0, 1)), w.float(), b, stride=2))
+    else:
+        T = n   # one clip of n frames
+        w, b = rnd(C, C, 3, 1, 1, scale=(3 * C) ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_conv_t3(w, b)
+        x5 = x3.float().view(1, T, S, 1, C).permute(0, 4, 1, 2, 3)
+        ref = F.conv3d(x5, w.float(), b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(n, S, C)
+        if kind == "conv_t3":
+            fn = lambda: ops.conv_t3(x3, pw, T, S)  # noqa: E731
+        else:
+            fn = lambda: ops.conv_t3(x3, pw, T, S, res2=x3, alpha=0.3, beta=1.0)  # noqa: E731
+            ref = 0.3 * ref + x3.float()
+    outs = {}
+    for cfg in (7, 4):
+        ops.TILE_CFG = cfg
+        try:
+            outs[cfg] = fn()
+        finally:
+            ops.TILE_CFG = 0
+    o7, o4 = outs[7], outs[4]
+    if isinstance(o7, tuple):
+        (o7, s7), (o4, s4) = o7, o4
+        assert s7.parts == s4.parts and torch.equal(s7.t, s4.t), "row-sum slabs differ"
+        _check_stats(s7, o7)
+    close(o7.reshape(ref.shape), ref, f"gemm_pipe {kind}")
+    assert torch.equal(o7, o4), "pipelined and sixteen-wave kernels must agree bit for bit"
+
+
+def test_gemm_pipe_is_what_the_launcher_runs_and_refusals():
+    """The launcher's own choice (vk_gemm_tile_choice) is the pipelined kernel wherever the 256x320 tile is, its split-K form included; what it
+    does not take (fused nearest-x2 upsample, halo frames of a frame-sharded run, fp32 output, two-source A) stays on the sixteen-wave kernels
+    and a forced tile_cfg 7 falls back without an error."""
+    import ctypes as C
+    from vista_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    n, H, W, Cc = 4, 18, 32, 320
+    x3 = rnd(n, H * W, Cc)
+    pw = ops.pack_conv3x3(rnd(Cc, Cc, 3, 3, scale=(9 * Cc) ** -0.5, seed=1), rnd(Cc, seed=2).float())
+    ref = _nchw2tok(F.conv2d(F.interpolate(_tok2nchw(x3, n, H, W), scale_factor=2, mode="nearest"), rnd(Cc, Cc, 3, 3, scale=(9 * Cc) ** -0.5, seed=1).float().cuda(),
+                             rnd(Cc, seed=2).float().cuda(), padding=1))
+    ops.TILE_CFG = 7
+    try:
+        up = ops.conv3x3(x3, pw, n, H, W, ups=2)[0]      # not taken: falls back
+    finally:
+        ops.TILE_CFG = 0
+    close(up, ref, "forced pipelined variant on an upsampling conv")
+    one = C.c_void_p(4096)
+    d = _lib.VkGemmDesc()
+    d.A = d.Wt = d.out = one
+    d.M, d.N, d.K, d.lda, d.ldc, d.alpha = 50 * 9216, 320, 2880, 2880, 320, 1.0
+    d.amode, d.epi = ops.AMODE_CONV3X3, ops.EPI_LINEAR
+    d.Cin, d.H, d.Wd, d.Hout, d.Wout, d.stride, d.ups = 320, 72, 128, 72, 128, 1, 1
+    assert lib.vk_gemm_tile_choice(C.byref(d)) == 7 * 16 + 1
+    d.ups = 2
+    d.Hout, d.Wout, d.M = 144, 256, 50 * 144 * 256
+    assert lib.vk_gemm_tile_choice(C.byref(d)) == 4 * 16 + 1
+
+
 # ------------------------------------------------------------------------------------------------ round 2: folded LayerNorm, row sums,
 # two-source (concat) loaders, rowvec2
 def _ln_ref(x, gamma, beta, eps=1e-5):
@@ -579,7 +699,7 @@ def _check_stats(st, out):
     assert (got - ref).abs().le(tol).all(), f"row sums off by {(got - ref).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("M,N,K", [(777, 320, 320), (300, 640, 1280), (513, 1280, 640), (100, 64, 128)])
 def test_linear_emit_rowstats(cfg, M, N, K):
     ops = _ops()
@@ -610,7 +730,7 @@ def test_rowstats(rows, C):
     _check_stats(ops.rowstats(big[:, C:]), big[:, C:])  # strided rows
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("M,C,N", [(600, 320, 640), (300, 1280, 1280), (130, 64, 192)])
 def test_linear_layernorm_fold(cfg, M, C, N):
     """Linear(LayerNorm(x)) with the norm folded into the GEMM: x has a LARGE row mean (the fold subtracts mean * colsum in the epilogue)."""
