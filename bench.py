@@ -430,7 +430,7 @@ def main():
                         _att.FP8[k] = True
                     dt8, _, _ = timed_loop(None, False, settle=2)
                     res["config5_fp8"] = {"value": args.steps / dt8, "unit": "steps/s", "ms_per_step": dt8 * 1e3 / args.steps,
-                                          "note": "same step, fp8(e4m3) FeedForward GEMMs, ResBlock convolutions, attention QK^T and attention-out projections; "
+                                          "note": "same step, fp8(e4m3) ResBlock convolutions, attention QK^T, and -- from block width 640 up, where fp8 still beats the bf16 kernels -- FeedForward GEMMs and attention-out projections; "
                                                   "parity: tests/test_fp8_gpu.py, tests/test_blocks_gpu.py"}
                 finally:
                     _att.FP8.update(saved)

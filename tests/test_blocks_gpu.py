@@ -161,6 +161,10 @@ def test_spatial_video_transformer_at_baseline_shape(name, C, H, W):
             continue
         with torch.no_grad(), _fp8(keys):
             out8 = blk(_tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W)
+        if C == 320 and keys == ["feedforward"]:
+            # level 0: config 5 keeps the fused bf16 FeedForward kernel (faster than the fp8 pair there and 15x closer to fp32, round 4)
+            assert torch.equal(out8, out), "config 5 must leave the level-0 FeedForwards on the fused bf16 kernel"
+            continue
         assert not torch.equal(out8, out), "the fp8 switch did not change the path"
         _report(f"[fp8 {'+'.join(keys)}] SpatialVideoTransformer " + name, _nchw(out8, T, H, W), ref, 4e-2, 6e-2, 0.0)
     with torch.no_grad():

@@ -310,12 +310,33 @@ def test_attention_branch_fp8_quantisation_error(n_img, heads, S):
     assert r < 5e-2
 
 
-@pytest.mark.parametrize("dim,M", [(320, 1200), (1280, 300)])
+def test_feedforward_config5_keeps_the_fused_bf16_kernel_at_width_320():
+    """Round 4: where the fused bf16 FeedForward kernel runs (level 0, width 320) config 5 keeps it -- it is faster than the fp8 pair there
+    (1.28 vs 1.38 ms at the BASELINE shape) and 15x closer to fp32 (tools/fp8_vs_bf16_probe.py): the switch must not change that block's result."""
+    ops = _ops()
+    from vista_amd.modules import attention
+    ff = attention.FeedForward(320, glu=True).cuda()
+    norm = torch.nn.LayerNorm(320).cuda()
+    x = (rnd(1200, 320) + 0.3).to(BF16).cuda()
+    pw_in, st = ff.pack_in_folded(norm, x.device), ops.rowstats(x)
+    plain = ff.forward_folded(x, st, pw_in, norm, res1=x)
+    attention.FP8["feedforward"] = True
+    try:
+        assert not ff._fp8()
+        cfg5 = ff.forward_folded(x, st, pw_in, norm, res1=x)
+        wide = attention.FeedForward(640, glu=True).cuda()
+        assert wide._fp8()
+    finally:
+        attention.FP8["feedforward"] = False
+    assert torch.equal(plain, cfg5)
+
+
+@pytest.mark.parametrize("dim,M", [(640, 1200), (1280, 300)])
 def test_feedforward_fp8_no_quantisation_pass(dim, M):
-    """FeedForward of config 5: LN+quant -> fp8 GEGLU (MX out) -> fp8 out-projection (MX in), vs the fp32 function. Re-stated tolerance
-    on the branch output (residual excluded): four e4m3 roundings in series -- x and W1 (3.6e-2 together, module docstring), the
-    value and the gate both carry that error into value*gelu(gate) (another ~3.6e-2), then h and W2 (2.6e-2 each):
-    sqrt(2 * 3.6^2 + 2 * 2.6^2) e-2 = 6.3e-2 expected, 6.5e-2 measured at dim 320 -> rel-L2 <= 8e-2."""
+    """FeedForward of config 5 (levels 1 / 2: width 640 / 1280): LN+quant -> fp8 GEGLU (MX out) -> fp8 out-projection (MX in), vs the fp32
+    function. Re-stated tolerance on the branch output (residual excluded): four e4m3 roundings in series -- x and W1 (3.6e-2 together,
+    module docstring), the value and the gate both carry that error into value*gelu(gate) (another ~3.6e-2), then h and W2 (2.6e-2 each):
+    sqrt(2 * 3.6^2 + 2 * 2.6^2) e-2 = 6.3e-2 expected, 6.5e-2 measured -> rel-L2 <= 8e-2."""
     ops = _ops()
     from vista_amd.modules import attention
     ff = attention.FeedForward(dim, glu=True).cuda()

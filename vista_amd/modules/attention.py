@@ -117,6 +117,7 @@ class GEGLU(nn.Module):
 # "attention": the spatial self-attention's score product in fp8 -- q | k leave the fused q|k|v projection's epilogue as MX fp8 (no pass) and
 # S^T = K Q^T is one scaled 32x32x64 fp8 MFMA per 32x32 block; "proj": additionally the attention output leaves the kernel as MX fp8 and the
 # attention-out projection (K = C) runs as an fp8 GEMM on it.
+FP8_PROJ_MIN_WIDTH = 640   # config 5: attention-out projections in fp8 from this block width up (round-4 probe: no gain at 320)
 FP8 = {"feedforward": os.environ.get("VISTA_FP8", "0") == "1", "conv": os.environ.get("VISTA_FP8_CONV", "0") == "1",
        "attention": os.environ.get("VISTA_FP8_ATTN", "0") == "1", "proj": os.environ.get("VISTA_FP8_PROJ", "0") == "1"}
 
@@ -145,10 +146,19 @@ class FeedForward(nn.Module, Packable):
         # the bf16 out-projection operand is packed on first use as well (_out_pack): plain for vk_gemm_bf16, or -- level 0, width 320 -- in the
         # fused kernel's own layout; whichever form the switches select at call time, so that flipping them restores the other path bit for bit
         pk = {}
-        if FP8["feedforward"]:
+        if self._fp8():
             pk["in8"] = ops.pack_geglu_fp8(self.net[0].proj.weight, self.net[0].proj.bias, dev)
             pk["out8"] = ops.pack_linear_fp8(self.net[2].weight, self.net[2].bias, dev)
         return pk
+
+    def _fp8(self):
+        """BASELINE config 5 for THIS FeedForward? Not where the fused bf16 kernel runs (level 0, width 320): round-4 same-box probe
+        (tools/fp8_vs_bf16_probe.py, 460800 tokens): fused bf16 1.28 ms at 2.7e-3 of fp32 against 1.38 ms at 4.0e-2 for the fp8 pair --
+        fp8 there costs time AND accuracy; levels 1 / 2: 0.93 vs 1.17 ms and 0.70 vs 1.03 ms, fp8 stays."""
+        if not FP8["feedforward"]:
+            return False
+        w2 = self.net[2].weight
+        return not (FF_FUSED and w2.shape[0] == ops.FF_FUSED_WIDTH and w2.shape[1] % 64 == 0 and 128 <= w2.shape[1] <= ops.FF_FUSED_MAX_HIDDEN)
 
     def _out_pack(self, pk):
         """(fused?, packed out-projection) for the bf16 path. Level-0 FeedForward (width 320): GEGLU + out-projection run as ONE kernel
@@ -170,7 +180,7 @@ class FeedForward(nn.Module, Packable):
         """y: LN output (M, dim). Returns net(y) fused with the residual / blend epilogue given by the caller (unfolded form: used
         by the fp8 experiment and by callers that already hold a normalised input)."""
         pk = self.packed()
-        if not FP8["feedforward"]:
+        if not self._fp8():
             if "in" not in pk:  # lives in the pack dict, so it is dropped with it whenever the parameters change
                 pk["in"] = ops.pack_geglu(self.net[0].proj.weight, self.net[0].proj.bias, self.net[2].weight.device)
             fused, pw_out = self._out_pack(pk)
@@ -188,7 +198,7 @@ class FeedForward(nn.Module, Packable):
     def forward_folded(self, x, stats, pw_in, norm, **epilogue):
         """net(LayerNorm(x)) with the LayerNorm folded into the GEGLU GEMM: x (M, dim) is the un-normalised residual stream,
         `stats` its RowStats, `pw_in` = pack_in_folded(norm). No normalised tensor is ever written (attention.py:524)."""
-        if FP8["feedforward"]:
+        if self._fp8():
             # BASELINE config 5: both GEMMs in fp8 e4m3 with NO stand-alone quantisation pass. LayerNorm + per-row quantisation is one
             # kernel (the normalised rows exist only as fp8), the GEGLU epilogue quantises its own output to MX fp8 (a power-of-two scale
             # per 32 columns), and the out-projection applies those block scales inside v_mfma_scale_f32_32x32x64_f8f6f4.
@@ -325,9 +335,12 @@ class BasicTransformerBlock(nn.Module, Packable):
             # output leaves as MX fp8 too and the out-projection below is an fp8 GEMM -- no quantisation pass anywhere.
             v, qk8, qks = ops.linear(x, pk["qkv"], ln=stats, mx8_cols=2 * C)
             nb = C // 32
+            # the fp8 out-projection only from width 640 up: at level 0 the bf16 one (K = N = 320: 0.26 ms) is as fast as the fp8 GEMM and
+            # 10x closer to fp32 (tools/fp8_vs_bf16_probe.py)
+            proj8 = FP8["proj"] and C >= FP8_PROJ_MIN_WIDTH
             r8 = ops.attn_spatial_fp8qk(qk8[:, :C], qk8[:, C:], qks[:, :nb], qks[:, nb:], v, n_img, self.n_heads, S, 0.0 if Q_LOG2 else scale,
-                                        mx_out=FP8["proj"])  # (pk["qkv"]'s query rows already carry scale * log2 e)
-            att8, att = (r8, None) if FP8["proj"] else (None, r8)
+                                        mx_out=proj8)  # (pk["qkv"]'s query rows already carry scale * log2 e)
+            att8, att = (r8, None) if proj8 else (None, r8)
         else:
             # ONE q|k|v GEMM (attention.py:344-346), LayerNorm(norm1) folded: x is read once and never as a normalised copy; the attention
             # kernel takes V as the third column block and transposes its tiles on the way out of LDS (no V^T tensor, no TRANS GEMM)
