@@ -370,7 +370,7 @@ def main():
     res = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": (("bf16 + fp8(e4m3) FeedForward GEMMs, ResBlock convolutions" + ("" if args.fp8_no_attn else ", attention QK^T and attention-out projections") + " [config 5]") if args.fp8 else
+        "dtype": (("bf16 + fp8(e4m3) ResBlock convolutions, FeedForward GEMMs from width 640 up" + ("" if args.fp8_no_attn else ", attention QK^T, attention-out projections from width 640 up") + " [config 5]") if args.fp8 else
                   "bf16 + fp8(e4m3) FeedForward GEMMs [config 5, FeedForward only]" if args.fp8_ff else "bf16"),
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (DRY RUN: gloo host-staged transport, ranks share one GPU -- not a result)",
         "config": {"workload": (f"{world}xMI355X " + layout(shard) +
