@@ -559,8 +559,8 @@ def test_splitk_conv3x3_and_temporal_conv():
 
 
 # ------------------------------------------------------------------------------------------------ round 4: the pipelined 256x320 kernel
-@pytest.mark.parametrize("kind", ["dense+res+stats", "qkv_lnfold", "ff_out+blend", "geglu_lnfold", "conv3x3+emb+res", "conv3x3_stride2", "conv3x3_asym",
-                                  "conv_t3", "conv_t3+blend"])
+@pytest.mark.parametrize("kind", ["dense+res+stats", "dense_strided_A", "qkv_lnfold", "ff_out+blend", "geglu_lnfold", "conv3x3+emb+res", "conv3x3_stride2",
+                                  "conv3x3_asym", "conv_t3", "conv_t3+blend"])
 @pytest.mark.parametrize("n,H,W,C", [(3, 20, 24, 320), (5, 9, 13, 640), (9, 36, 64, 320)])   # ragged last tile, tiles spanning 3-4 images, > 256 tiles
 def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
     """gemm_pipe.hip (VkGemmDesc.tile_cfg = 7: eight waves, 64x160 wave tiles, fragments double-buffered across the K-step barrier, the next
@@ -581,6 +581,13 @@ def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
         pw = ops.pack_linear(w, b)
         fn = lambda: ops.linear(x, pw, res1=res, rowvec=rv, rows_per_vec=S, emit_stats=True)  # noqa: E731
         ref = x.float() @ w.float().t() + b + res.float() + rv.repeat_interleave(S, 0)
+    elif kind == "dense_strided_A":   # A is a column block of a wider tensor (lda = 3C): the last tile's buffer range ends inside the last row
+        wide = rnd(M, 3 * C, seed=11)
+        xs = wide[:, C:2 * C]
+        w, b = rnd(C, C, scale=C ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda: ops.linear(xs, pw, res1=res)  # noqa: E731
+        ref = xs.float() @ w.float().t() + b + res.float()
     elif kind == "qkv_lnfold":
         nrm = _Norm(C, 7)
         w, b = rnd(3 * C, C, scale=C ** -0.5, seed=1), rnd(3 * C, seed=2).float()
