@@ -1,7 +1,7 @@
 # Round-4 measurement set in ONE gpurun call: default bench line, rocprofv3 kernel trace of the bench, per-step kernel table, SQ counters of the
 # fused FeedForward / level-0 GEMM family, HBM traffic of the level-0 attention and the fused FeedForward.   usage (GPU box): bash tools/prof_r04.sh
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04d
+O=$R/gpurun_out/r04g
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_default.log 2>&1; grep '^{' $O/bench_default.log > $O/r04_bench_default.json
