@@ -37,7 +37,7 @@ typedef struct VkGemmDesc {
                             CONV3D (3x3x3, pad 1 over [frames][H][Wd][Cin], K = 27*Cin): T = frames per clip        */
     int32_t tile_cfg;    /* 0 = auto; forced variants (tests / tuning): 1 = 128x128, 2 = 256x128, 3 = 256x256, 4 = 256x320 (sixteen waves),
                             5 = 128x160 (two workgroups per CU; DENSE LINEAR), 6 = the weight-stationary streaming kernel (K = 320, N = 320 / 640 /
-                            960), 7 = 256x320 eight-wave pipelined kernel (DENSE / CONV3X3 without upsample / TEMPORAL3 without halos x LINEAR,
+                            960), 7 = 256x320 eight-wave pipelined kernel (DENSE / CONV3X3 / TEMPORAL3 without halos x LINEAR, bf16 out,
                             DENSE x GEGLU; bitwise equal to 4). A variant that does not take the problem falls back to the launcher's choice.
                             Weight rows are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.                          */
     const void* halo_prev; /* TEMPORAL3, frame-sharded runs: bf16 [clips][S][Cin] frame preceding / following the local frame range   */

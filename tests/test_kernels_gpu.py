@@ -560,7 +560,7 @@ def test_splitk_conv3x3_and_temporal_conv():
 
 # ------------------------------------------------------------------------------------------------ round 4: the pipelined 256x320 kernel
 @pytest.mark.parametrize("kind", ["dense+res+stats", "dense_strided_A", "qkv_lnfold", "ff_out+blend", "geglu_lnfold", "conv3x3+emb+res", "conv3x3_stride2",
-                                  "conv3x3_asym", "conv_t3", "conv_t3+blend"])
+                                  "conv3x3_asym", "conv3x3_ups2", "conv_t3", "conv_t3+blend"])
 @pytest.mark.parametrize("n,H,W,C", [(3, 20, 24, 320), (5, 9, 13, 640), (9, 36, 64, 320)])   # ragged last tile, tiles spanning 3-4 images, > 256 tiles
 def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
     """gemm_pipe.hip (VkGemmDesc.tile_cfg = 7: eight waves, 64x160 wave tiles, fragments double-buffered across the K-step barrier, the next
@@ -616,6 +616,9 @@ def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
         if kind == "conv3x3+emb+res":
             fn = lambda: ops.conv3x3(x3, pw, n, H, W, rowvec=rv, res1=x3)[0]  # noqa: E731
             ref = _nchw2tok(F.conv2d(xn, w.float(), b, padding=1)) + rv[:, None, :] + x3.float()
+        elif kind == "conv3x3_ups2":   # Upsample.forward: nearest x2, then conv (openaimodel.py:100-102), the upsample fused into the loader
+            fn = lambda: ops.conv3x3(x3, pw, n, H, W, ups=2, rowvec=rv)[0]  # noqa: E731
+            ref = _nchw2tok(F.conv2d(F.interpolate(xn, scale_factor=2, mode="nearest"), w.float(), b, padding=1)) + rv[:, None, :]
         elif kind == "conv3x3_stride2":
             if H % 2 or W % 2:
                 pytest.skip("stride 2 needs even H, W")
@@ -654,9 +657,9 @@ def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
 
 
 def test_gemm_pipe_is_what_the_launcher_runs_and_refusals():
-    """The launcher's own choice (vk_gemm_tile_choice) is the pipelined kernel wherever the 256x320 tile is, its split-K form included; what it
-    does not take (fused nearest-x2 upsample, halo frames of a frame-sharded run, fp32 output, two-source A) stays on the sixteen-wave kernels
-    and a forced tile_cfg 7 falls back without an error."""
+    """The launcher's own choice (vk_gemm_tile_choice) is the pipelined kernel wherever the 256x320 tile is, its split-K form and the fused
+    nearest-x2 upsample included; what it does not take (halo frames of a frame-sharded run, fp32 output, two-source A) stays on the sixteen-wave
+    kernels and a forced tile_cfg 7 falls back without an error."""
     import ctypes as C
     from vista_amd import _lib
     ops = _ops()
@@ -668,10 +671,10 @@ def test_gemm_pipe_is_what_the_launcher_runs_and_refusals():
                              rnd(Cc, seed=2).float().cuda(), padding=1))
     ops.TILE_CFG = 7
     try:
-        up = ops.conv3x3(x3, pw, n, H, W, ups=2)[0]      # not taken: falls back
+        up = ops.conv3x3(x3, pw, n, H, W, ups=2, out_f32=True)[0]      # fp32 output: not taken, falls back
     finally:
         ops.TILE_CFG = 0
-    close(up, ref, "forced pipelined variant on an upsampling conv")
+    close(up, ref, "forced pipelined variant on a launch it does not take")
     one = C.c_void_p(4096)
     d = _lib.VkGemmDesc()
     d.A = d.Wt = d.out = one
@@ -681,6 +684,9 @@ def test_gemm_pipe_is_what_the_launcher_runs_and_refusals():
     assert lib.vk_gemm_tile_choice(C.byref(d)) == 7 * 16 + 1
     d.ups = 2
     d.Hout, d.Wout, d.M = 144, 256, 50 * 144 * 256
+    assert lib.vk_gemm_tile_choice(C.byref(d)) == 7 * 16 + 1
+    d.halo_prev = one   # (a TEMPORAL3 field: any loader the kernel does not take)
+    d.amode, d.K, d.T, d.S = ops.AMODE_TEMPORAL3, 960, 25, 144 * 256
     assert lib.vk_gemm_tile_choice(C.byref(d)) == 4 * 16 + 1
 
 

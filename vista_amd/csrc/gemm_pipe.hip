@@ -105,13 +105,19 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
                 const int rem = m - img * hw;
                 const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
                 const int y0 = oy * p.stride - (p.asym_pad ? 0 : 1), x0 = ox * p.stride - (p.asym_pad ? 0 : 1);
-                // tap (0, 0); wraps for y0 / x0 = -1, where it is only ever used with a valid tap's offset added
-                voff_a[i] = ((unsigned)((img * p.H + y0) * p.Wd + x0) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
+                // Fused nearest x2 upsample of the source (ups = 2, stride 1; openaimodel.py:100-102): tap (ky, kx) of output pixel (oy, ox) reads
+                // source pixel ((oy - 1 + ky) >> 1, (ox - 1 + kx) >> 1) = (oy >> 1) - 1 + ((ky + 1 + (oy & 1)) >> 1), likewise in x: the row /
+                // column parities ride in amask's top byte and the lane offset is that of source pixel ((oy >> 1) - 1, (ox >> 1) - 1)
+                const int sh = p.ups - 1;
+                const int ry = sh ? ((y0 + 1) >> 1) - 1 : y0, rx = sh ? ((x0 + 1) >> 1) - 1 : x0;
+                if (sh) amask |= (unsigned)(((y0 + 1) & 1) | (((x0 + 1) & 1) << 1)) << (24 + 2 * i);
+                // tap (0, 0); wraps for ry / rx = -1, where it is only ever used with a valid tap's offset added
+                voff_a[i] = ((unsigned)((img * p.H + ry) * p.Wd + rx) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
                 unsigned mk = 0;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    if (m < p.M && y0 + t >= 0 && y0 + t < p.H) mk |= 1u << t;
-                    if (x0 + t >= 0 && x0 + t < p.Wd) mk |= 8u << t;
+                    if (m < p.M && y0 + t >= 0 && y0 + t < (p.H << sh)) mk |= 1u << t;
+                    if (x0 + t >= 0 && x0 + t < (p.Wd << sh)) mk |= 8u << t;
                 }
                 amask |= mk << (6 * i);
             }
@@ -147,9 +153,15 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, v, (unsigned)kb, 0, 0);
         } else if (AMODE == AMODE_CONV3X3) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            const unsigned tapoff = (unsigned)((ky * p.Wd + kx) * p.Cin) * 2u;
             const bool ok = ((amask >> (6 * j + ky)) & (amask >> (6 * j + 3 + kx)) & 1u) != 0;
-            const unsigned v = ok ? voff_a[j] + tapoff : P_OOB;
+            unsigned v;
+            if (p.ups == 2) {   // (kernel-uniform) per-lane tap offset: the source step of a tap depends on the output pixel's parity
+                const unsigned dy = (((amask >> (24 + 2 * j)) & 1u) + (unsigned)(ky + 1)) >> 1, dx = (((amask >> (25 + 2 * j)) & 1u) + (unsigned)(kx + 1)) >> 1;
+                v = voff_a[j] + (dy * (unsigned)p.Wd + dx) * ((unsigned)p.Cin * 2u);
+            } else {
+                v = voff_a[j] + (unsigned)((ky * p.Wd + kx) * p.Cin) * 2u;
+            }
+            if (!ok) v = P_OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, dst, 16, v, (unsigned)c0b, 0, 0);
         } else {
             const unsigned tapoff = (unsigned)((tap - 1) * p.S * p.Cin) * 2u;
@@ -404,7 +416,7 @@ extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d) {
     if ((unsigned long long)PBN * d->K * 2ull >= P_LIMIT) return 0;
     if (d->amode == AMODE_DENSE) return ((unsigned long long)PBM * d->lda * 2ull < P_LIMIT) ? 1 : 0;
     if (d->amode == AMODE_CONV3X3) {
-        if (d->ups != 1) return 0;   // the fused nearest x2 upsample's source pixel is not affine in the tap
+        if (d->ups == 2 && (d->stride != 1 || d->asym_pad)) return 0;   // (the fused nearest x2 upsample comes with stride 1, pad 1 only)
         const long long hw = (long long)d->Hout * d->Wout;
         if (hw <= 0 || (d->M % hw) != 0) return 0;
         return ((unsigned long long)(d->M / hw) * d->H * d->Wd * d->Cin * 2ull < P_LIMIT) ? 1 : 0;
