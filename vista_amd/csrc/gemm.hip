@@ -44,7 +44,10 @@ namespace {
 // 128x160 two-per-CU tiles for DENSE LINEAR GEMMs with N <= K <= this. Same-box sweep (profiles/r03_tile5_sweep.txt): K = N = 320 projections
 // +20 % (0.305 -> 0.255 ms, 3.5 TB/s algorithmic), K = N = 640 +14 %, K = N = 1280 -7 %; N = 3K (q|k|v) -15 % and K = 4N (FF out) -3..-18 %: the
 // extra column tiles re-read the activations / the deep K-loop is MFMA-bound and wants the big tile.
-constexpr int TILE5_MAX_K_DEFAULT = 640;
+// Round 4: at K = N = 640 the pipelined 256x320 kernel (gemm_pipe.hip) beats the 128x160 tile (level 1, 115200 rows, + residual + row sums:
+// 0.166 vs 0.175 ms, profiles/r04_gemm_pipe.txt), so the default bound is 320 now; the 128x160 tile keeps K = N = 320 (0.240 vs 0.248 ms) and the
+// under-filled small problems of the rule further down.
+constexpr int TILE5_MAX_K_DEFAULT = 320;
 
 __device__ uint4 g_zero16;  // source of the zero fill for out-of-image conv taps on the LDS-DMA path (zero-initialised)
 
