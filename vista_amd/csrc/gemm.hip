@@ -12,8 +12,11 @@
 // went through the fabric: 2.65 GB fetched per level-0 conv launch for 0.3 GB of input (rocprofv3 FETCH_SIZE, profiles/r02_pmc_traffic.txt).
 //
 // Tiling (template): block tile BM x BN x 64 with WM x WN waves, each wave FM x FN MFMA 32x32x16 bf16 tiles, fp32 accumulate.
-// Every layout keeps a wave at <= 128 VGPRs, i.e. FOUR waves per SIMD: co-resident waves, not a hand-built phase schedule, are
-// what covers LDS-read latency, LDS-DMA issue and the per-K-step barrier on this chip (profiles/r01_vendor_blas_yardstick.txt).
+// Every layout of THIS file keeps a wave at <= 128 VGPRs, i.e. FOUR waves per SIMD: co-resident waves cover LDS-read latency, LDS-DMA
+// issue and the per-K-step barrier (profiles/r01_vendor_blas_yardstick.txt). Round 4 added the opposite design for the 256x320 tile --
+// eight waves, 256 VGPRs, a hand-ordered K-step (gemm_pipe.hip: +14-17 % on the convolutions) -- which the launcher below now prefers
+// wherever it takes the problem (tile variant 7), and two special-purpose kernels (gemm_stream.hip: K = 320 projections; ff_fused.hip:
+// the level-0 FeedForward); the kernels here remain for the other tiles, CONV3D, fp32 output, two-source A, halo frames and TRANS.
 //   256x320 (16 waves 8x2, wave tile 32x160, single-buffered fragments)  N a multiple of 320 (every channel count of the
 //                                            shipped UNet): no padded columns, the conv gather of A runs once per 320 channels
 //   256x256 (16 waves 4x4, wave tile 64x64)  GEGLU and N % 320 != 0

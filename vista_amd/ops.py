@@ -180,7 +180,7 @@ def pack_conv_t3(weight, bias=None, device="cuda", cin_pad=None):
 
 
 # ---------------------------------------------------------------------------------------------- GEMM family
-TILE_CFG = 0  # 0 = auto; tests force 1/2/3/4 to cover every block-tile variant
+TILE_CFG = 0  # 0 = auto; tests force 1..7 to cover every block-tile variant (include/vista_hip.h, VkGemmDesc.tile_cfg)
 
 
 SPLITK_WS_BYTES = int(os.environ.get("VISTA_SPLITK_WS_MB", "160")) << 20  # fp32 split-K workspace per (device, stream) (0 disables split-K)
