@@ -1,18 +1,21 @@
-// Eight-wave pipelined 256x320 variant of the tiled bf16 GEMM (tile_cfg 7): DENSE / CONV3X3 / TEMPORAL3 loaders x LINEAR epilogue, bf16 out.
+// Eight-wave pipelined 256x320 variant of the tiled bf16 GEMM (tile_cfg 7): DENSE / CONV3X3 (stride 1 | 2, asymmetric pad, fused nearest x2
+// upsample) / TEMPORAL3 (no halo frames) loaders x LINEAR epilogue, DENSE x GEGLU, and the split-K form of the LINEAR ones; bf16 out.
 // Same math, LDS image, fragment layout and epilogues (gemm_common.h) as gemm.hip's sixteen-wave 256x320 kernel -- results are bitwise the
-// same -- but the K-step is written for the matrix pipe instead of for occupancy:
+// same -- but the K-step is written for the matrix pipe instead of for occupancy (measurements: profiles/r04_gemm_pipe.txt):
 //   * eight waves, wave tile 64 x 160 (2 activation x 5 weight fragments, 160 accumulator registers, 256-VGPR budget, two waves per SIMD):
 //     7 ds_read_b128 per 10 MFMAs instead of 6 per 5;
-//   * fragments double-buffered ACROSS the K-step barrier: the last k-substep's ten MFMAs are issued after the barrier and
-//     cover the first fragment reads of the next stage, so no LDS latency is exposed anywhere in the loop (the sixteen-wave kernel waits on lgkmcnt(0) before
-//     almost every MFMA pair and relies on its four waves per SIMD to fill the holes);
-//   * the nine LDS-DMA pieces of the next tile are issued BETWEEN the MFMAs of the first two k-substeps, one per MFMA pair. An LDS-DMA issue
-//     stalls its wave for ~120 cycles (profiles/r04_ff_fused_notes.txt); at the head of the K-step, where the other variants issue them, both
-//     waves of a SIMD stall together and the pipe idles, here the partner wave's MFMAs run in the gap;
+//   * fragments double-buffered ACROSS the K-step barrier: the last k-substep's ten MFMAs are issued after the barrier and cover the first
+//     fragment reads of the next stage, so no LDS latency is exposed anywhere in the loop (the sixteen-wave kernel waits on lgkmcnt(0)
+//     before almost every MFMA pair and relies on its four waves per SIMD to fill the holes);
+//   * the nine LDS-DMA pieces of the next K-step (activation pieces first: they are the ones that may come from HBM) are issued BETWEEN the
+//     MFMAs of the first k-substep, one after each MFMA. An LDS-DMA issue stalls its wave for ~120 cycles (profiles/r04_ff_fused_notes.txt);
+//     interleaved, the partner wave's MFMAs run in the gaps (worth 1-2 % over issuing all nine ahead of the MFMAs);
 //   * the pieces are BUFFER loads (buffer_load_dwordx4 ... lds): a wave-uniform resource per operand in SGPRs, ONE 32-bit per-lane offset for
 //     the weights and one per activation row group, everything that changes per piece / K-step / tap in scalar registers. Out-of-image conv
 //     taps, frames outside the window and rows past M are out-of-range offsets, which the hardware returns as zeros: no clamping, no zero
-//     word, no 64-bit per-lane pointers (the sixteen-wave kernel keeps nine of them live across the loop).
+//     word, no 64-bit per-lane pointers (the sixteen-wave kernel keeps nine of them live across the loop);
+//   * LINEAR launches run one tile per workgroup (a workgroup that ends does not wait for its stores); GEGLU launches walk the tile list with
+//     256 resident workgroups and stage the next tile's first K-step before the epilogue.
 // Internal entry points, called by gemm.hip's launcher.
 #include <stdlib.h>
 
