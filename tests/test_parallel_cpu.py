@@ -116,6 +116,36 @@ def test_frame_pixel_exchange_thread_ranks(P, T, S):
     assert not errs, errs
 
 
+@pytest.mark.parametrize("P,T,S", [(4, 25, 18), (4, 13, 144), (3, 7, 10)])
+def test_one_clip_groups_skip_the_pixel_side_gathers(P, T, S):
+    """B = 1 (one CFG half per frame-shard group: the 8-GPU hybrid layout): the per-peer blocks of the pixel-sharded side are whole frame
+    ranges in global order, so the receive buffer of to_pixels is the result and the input of to_frames is the send buffer -- the plan holds no
+    index for them (round 4; two of the four row gathers of a temporal block's round trip) and the exchange is still exact. B = 2 keeps all four."""
+    C = 8
+    for B in (1, 2):
+        X = torch.randn(B, T, S, C)
+        shared = ThreadComm.Shared(P)
+        errs, plans = [], {}
+
+        def run(rank, B=B, X=X, shared=shared, errs=errs, plans=plans):
+            try:
+                sh = FrameShard(T, ThreadComm(shared, rank), B=B)
+                _check_rank(sh, X)
+                plans[rank] = sh._plan(S, torch.device("cpu"))
+            except Exception as e:  # noqa: BLE001
+                errs.append((rank, repr(e)))
+                shared.barrier.abort()
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(P)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        for r in range(P):
+            pl = plans[r]
+            assert (pl["unpack_fp"] is None) == (B == 1) and (pl["pack_pf"] is None) == (B == 1), (B, r)
+            assert pl["pack_fp"] is not None and pl["unpack_pf"] is not None   # the frame-sharded side always permutes (P > 1)
+
+
 def _gloo_worker(rank, world, port, T, S):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -210,6 +210,11 @@ class ThreadComm:
         return [g.clone() for g in got]
 
 
+def _rows(t, index):
+    """Row gather of an exchange plan; None = the identity (the tensor itself, made contiguous if it is not)."""
+    return t.contiguous() if index is None else t.index_select(0, index)
+
+
 class FrameShard:
     """Frame / pixel partition of one sampling window and the exchanges between the two layouts.
 
@@ -272,9 +277,15 @@ class FrameShard:
         unpack_pf = torch.empty(B, t_l, S, dtype=torch.int64)
         for q in range(P):
             unpack_pf[:, :, so[q]:so[q + 1]] = ro2[q] + ((ar(B)[:, None, None] * t_l + ar(t_l)[None, :, None]) * sc[q] + ar(sc[q])[None, None, :])
+        # A gather whose index is the identity is skipped (None): with one clip per group (B = 1: the CFG x frame hybrid, the 8-GPU default)
+        # the per-peer blocks of the pixel-sharded side are whole frame ranges, already in global frame order -- the receive buffer of
+        # to_pixels IS the result and the send buffer of to_frames IS the input; only the frame-sharded side needs its row gather.
+        def ident(ix):
+            ix = ix.reshape(-1)
+            return None if torch.equal(ix, ar(ix.numel())) else ix.to(device)
         plan = {"sc": sc, "s_r": s_r,
-                "pack_fp": pack_fp.to(device), "unpack_fp": unpack_fp.reshape(-1).to(device),
-                "pack_pf": pack_pf.to(device), "unpack_pf": unpack_pf.reshape(-1).to(device)}
+                "pack_fp": ident(pack_fp), "unpack_fp": ident(unpack_fp),
+                "pack_pf": ident(pack_pf), "unpack_pf": ident(unpack_pf)}
         self._plans[key] = plan
         return plan
 
@@ -376,11 +387,11 @@ class FrameShard:
         assert n == B * self.t_local
         pl = self._plan(S, x.device)
         sc, s_r = pl["sc"], pl["s_r"]
-        send = x.reshape(n * S, C).index_select(0, pl["pack_fp"])
+        send = _rows(x.reshape(n * S, C), pl["pack_fp"])
         in_splits, out_splits = self.exchange_splits(S, C)["to_pixels"]
         recv = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
         self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
-        return recv.view(-1, C).index_select(0, pl["unpack_fp"]).view(B * self.T, s_r, C)
+        return _rows(recv.view(-1, C), pl["unpack_fp"]).view(B * self.T, s_r, C)
 
     def to_frames(self, y, S):
         """(B*T, S_r, C) pixel-sharded -> (B*t_local, S, C) frame-sharded."""
@@ -390,11 +401,11 @@ class FrameShard:
         pl = self._plan(S, y.device)
         sc = pl["sc"]
         assert s_r == pl["s_r"]
-        send = y.reshape(n * s_r, C).index_select(0, pl["pack_pf"])
+        send = _rows(y.reshape(n * s_r, C), pl["pack_pf"])
         in_splits, out_splits = self.exchange_splits(S, C)["to_frames"]
         recv = torch.empty(sum(out_splits), dtype=y.dtype, device=y.device)
         self.comm.all_to_all(recv, send.reshape(-1), out_splits, in_splits)
-        return recv.view(-1, C).index_select(0, pl["unpack_pf"]).view(B * self.t_local, S, C)
+        return _rows(recv.view(-1, C), pl["unpack_pf"]).view(B * self.t_local, S, C)
 
     # ---- chunked way back (pixels -> frames) for compute / transport overlap
     def pixel_chunks(self, S, chunks):
