@@ -1,5 +1,8 @@
 """Pipelined eight-wave 256x320 GEMM variant (ops.TILE_CFG = 7, vista_amd/csrc/gemm_pipe.hip) against the sixteen-wave 256x320 kernel (TILE_CFG = 4):
-bitwise comparison on the BASELINE shapes and on ragged ones, then timing.   usage: python tools/gemm_pipe_probe.py [images]"""
+bitwise comparison on the BASELINE shapes and on ragged ones, then timing, plus the launcher's own choice (TILE_CFG = 0) beside them.
+Environment: PROBE_FAST=n (first n shape sets), PROBE_SMALL=1 (level 3 / one rank's sizes), PROBE_KINDS=a,b (case filter), PROBE_SEED, PROBE_TIMING=1 (library
+built with -DPIPE_TIMING: s_memtime phase sums), PROBE_CHK=1 (checksums of the inputs and of every packed weight after every launch: found the
+out-of-bounds row-sum write of round 4).   usage: python tools/gemm_pipe_probe.py [images]"""
 import os
 import sys
 
@@ -59,7 +62,7 @@ def main():
             if os.environ.get("PROBE_CHK") and fn.__defaults__:
                 pwd = fn.__defaults__[0]
                 print("   packed:", {k: (tuple(getattr(pwd, k).shape), bool(torch.isfinite(getattr(pwd, k).float()).all())) for k in ("wt", "bias", "colsum") if torch.is_tensor(getattr(pwd, k, None))}, flush=True)
-            for cfg in (4, 7, 0, 0):   # 0 = the launcher's own choice (stream-K remainder where it pays), twice: run-to-run bitwise check
+            for cfg in (4, 7, 0, 0):   # 0 = the launcher's own choice (split-K, 128x160 tiles, the streaming kernel ... where its rules pick them), twice: run-to-run bitwise check
                 ops.TILE_CFG = cfg
                 out.setdefault(cfg, []).append([t.clone() for t in flat(fn())])
                 if os.environ.get("PROBE_CHK"):
