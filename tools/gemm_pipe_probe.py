@@ -96,9 +96,11 @@ def main():
                 torch.cuda.synchronize()
                 ws = ops._splitk_workspace(ops._stream())[:64].view(8, 8).cpu()
                 ops.TILE_CFG = 0
-                for w in (0, 5):
-                    d, b, per, ks, pro, loop, epi = ws[w, :7].tolist()
-                    print(f"      wave {w}: K-steps {int(ks) + 2}  period {per / max(ks, 1):.0f}  own-DMA wait {d / (ks + 1):.0f}  barrier wait {b / (ks + 1):.0f} per K-step;  prologue {pro:.0f}  loop {loop:.0f}  epilogue {epi:.0f} ticks")
+                for w in (0, 5):   # per wave of workgroup 8: [own-DMA wait, barrier wait, K-steps timed, K-loops, epilogues, kernel] in s_memtime ticks
+                    d, b, ks, loop, epi, tot = ws[w, :6].tolist()
+                    ks = max(ks, 1.0)
+                    print(f"      wave {w}: K-steps timed {int(ks)}  K-loop {loop / ks:.0f} ticks per K-step  own-DMA wait {d / ks:.0f}  barrier wait {b / ks:.0f};  "
+                          f"K-loops {loop:.0f}  epilogues {epi:.0f}  kernel {tot:.0f} ticks")
             err = max((a.float() - b.float()).abs().max().item() for a, b in zip(out[4], out[7]))
             print(f"C {C:5d} M {M:7d} {name:18s} bitwise {'OK ' if same else 'DIFF'} max|d| {err:.3g}   cfg4 {ms[4]:.4f} ms  cfg7 {ms[7]:.4f} ms  "
                   f"{100 * (ms[4] / ms[7] - 1):+.1f} %   {flop / ms[7] / 1e9:.0f} TFLOP/s" + (f"   cfg3 {ms[3]:.4f} ms" if 3 in ms else "") +
