@@ -53,15 +53,18 @@ def build_model(model_channels, seed=0):
 
 
 def cpu_baseline(net, T, H, W, seed):
-    """CPU leg, on the host cores of the GPU box, bounded to about a minute: two REAL full-size pieces of the timed step run through the fp32 CPU
-    restatement of the reference (oracle/vista_oracle.py, pinned to the reference's own modules at <= 2e-4 of output rms by
-    tests/test_oracle_cpu.py; /root/reference does not exist on the GPU box, so kind is always "port"), with the network's own weights, one clip
-    (T frames) of the CFG pair each, at the full 72x128 latent:
-      (a) the first level-0 SpatialVideoTransformer (input_blocks.1.1: width 320, 9216 tokens per frame: spatial + temporal transformer block),
-      (b) the first level-0 VideoResBlock (input_blocks.1.0: 2-D ResBlock + 3x1x1 temporal ResBlock + blend).
-    Their FLOPs are counted by torch's flop counter. The ten level-0 (transformer, ResBlock) pairs of a step are ~39 % of its FLOPs (`share_of_step_flop` in the output); the whole step is
-    estimated as (step FLOPs) / (blended rate of the two pieces). Nothing is read from earlier rounds' files. Also returns the HIP path's
-    relative L2 error against the oracle on both pieces (the same modules of the timed network, same inputs)."""
+    """CPU leg, on the host cores of the GPU box, bounded to about a minute: REAL full-size pieces of the timed step run through the fp32 CPU
+    restatement of the reference (oracle/vista_oracle.py -- the ORACLE, a restatement, NOT the reference itself: /root/reference does not
+    exist on the GPU box, so kind is always "port"; the oracle is pinned to the reference's own modules at <= 2e-4 of output rms by
+    tests/test_oracle_cpu.py and calls the same ATen ops), with the network's own weights, one clip (T frames) of the CFG pair each:
+      level 0 (width 320, 72x128):  input_blocks.1.1 SpatialVideoTransformer (spatial + temporal transformer block) and input_blocks.1.0
+                                    VideoResBlock (2-D ResBlock + 3x1x1 temporal ResBlock + blend),
+      level 1 (width 640, 36x64):   input_blocks.5.1 / input_blocks.5.0,
+      level 2 (width 1280, 18x32):  input_blocks.8.1 / input_blocks.8.0.
+    Their FLOPs are counted by torch's flop counter. A step holds 2 clips x 5 such (transformer, ResBlock) pairs per level (2 input + 3 output
+    blocks; the output blocks' first convolutions are wider, so the share below is a slight under-count): `share_of_step_flop` of the step is
+    measured, the rest is estimated at the blended rate of the measured pieces. Nothing is read from earlier rounds' files. Also returns the HIP
+    path's relative L2 error against the oracle on every piece (the same modules of the timed network, same inputs)."""
     from torch.utils.flop_counter import FlopCounterMode
     from oracle import vista_oracle as O
     from vista_amd import ops, synth
@@ -69,38 +72,44 @@ def cpu_baseline(net, T, H, W, seed):
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
     g = torch.Generator().manual_seed(seed)
     bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731  (inputs representable in the HIP path's storage type)
-    x = bf(torch.randn(T, 320, H, W, generator=g))
     emb = bf(torch.randn(T, 1280, generator=g) * 0.7)
     w = synth.window_inputs(T=T, H=2, W=2, seed=seed, trajectory=[0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2])
     ctx = bf(w["c"]["crossattn"])   # (T, 1, 3456): CLIP-like token + action sinusoids
-    pieces = {}
-    tok = lambda t: t.permute(0, 2, 3, 1).reshape(T, H * W, -1).to(torch.bfloat16).cuda().contiguous()  # noqa: E731
-    nchw = lambda t: t.float().cpu().view(T, H, W, -1).permute(0, 3, 1, 2)  # noqa: E731
     rel = lambda a, r: ((a - r).pow(2).sum().sqrt() / r.pow(2).sum().sqrt()).item()  # noqa: E731
+    frame_idx = torch.arange(T, dtype=torch.float32).cuda()
+    ctx_dev = ops.cast_to_bf16(ctx.reshape(T, -1).cuda())
+    emb_dev = torch.nn.functional.silu(emb).to(torch.bfloat16).cuda()
+    pieces, parity = [], {}
     with torch.no_grad():
-        for name, fn in (("level-0 SpatialVideoTransformer (input_blocks.1.1)", lambda: O.spatial_video_transformer(sd, "input_blocks.1.1", x, ctx, T, True)),
-                         ("level-0 VideoResBlock (input_blocks.1.0)", lambda: O.video_resblock(sd, "input_blocks.1.0", x, emb, T))):
-            with FlopCounterMode(display=False) as fc:
-                t0 = time.perf_counter()
-                ref = fn()
-                dt = time.perf_counter() - t0
-            pieces[name] = {"seconds": dt, "flop": float(fc.get_total_flops()), "ref": ref}
-        frame_idx = torch.arange(T, dtype=torch.float32).cuda()
-        out_a = net.input_blocks[1][1](tok(x), ops.cast_to_bf16(ctx.reshape(T, -1).cuda()), frame_idx, T, H, W)
-        out_b = net.input_blocks[1][0](tok(x), torch.nn.functional.silu(emb).to(torch.bfloat16).cuda(), T, H, W)
-    (na, pa), (nb, pb) = pieces.items()
-    parity = {na: rel(nchw(out_a), pa["ref"]), nb: rel(nchw(out_b), pb["ref"])}
-    f_meas = pa["flop"] + pb["flop"]
-    t_meas = pa["seconds"] + pb["seconds"]
+        for level, (blk, width, h, wd) in enumerate(((1, 320, H, W), (5, 640, H // 2, W // 2), (8, 1280, H // 4, W // 4))):
+            x = bf(torch.randn(T, width, h, wd, generator=g))
+            tok = x.permute(0, 2, 3, 1).reshape(T, h * wd, -1).to(torch.bfloat16).cuda().contiguous()
+            nchw = lambda t: t.float().cpu().view(T, h, wd, -1).permute(0, 3, 1, 2)  # noqa: E731
+            for name, fn, hip in ((f"level-{level} SpatialVideoTransformer (input_blocks.{blk}.1)",
+                                   lambda: O.spatial_video_transformer(sd, f"input_blocks.{blk}.1", x, ctx, T, True),
+                                   lambda: net.input_blocks[blk][1](tok, ctx_dev, frame_idx, T, h, wd)),
+                                  (f"level-{level} VideoResBlock (input_blocks.{blk}.0)",
+                                   lambda: O.video_resblock(sd, f"input_blocks.{blk}.0", x, emb, T),
+                                   lambda: net.input_blocks[blk][0](tok, emb_dev, T, h, wd))):
+                with FlopCounterMode(display=False) as fc:
+                    t0 = time.perf_counter()
+                    ref = fn()
+                    dt = time.perf_counter() - t0
+                pieces.append((name, dt, float(fc.get_total_flops())))
+                parity[name] = rel(nchw(hip()), ref)
+                del ref
+    f_meas = sum(f for _, _, f in pieces)
+    t_meas = sum(t for _, t, _ in pieces)
     rate = f_meas / t_meas
     est_s = FLOP_PER_STEP_CFG / rate
-    share = 2 * 5 * f_meas / FLOP_PER_STEP_CFG   # 2 clips x 5 level-0 (transformer, ResBlock) pairs per forward
+    share = 2 * 5 * f_meas / FLOP_PER_STEP_CFG   # 2 clips x 5 (transformer, ResBlock) pairs per level and forward
     return {"value": 1.0 / est_s, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"two full-size pieces of the step timed in this run on the host ({cores} threads), one 25-frame clip each at latent {H}x{W}, network weights: "
-                      f"{na}: {pa['seconds']:.1f} s, {pa['flop'] / 1e12:.2f} TFLOP; {nb}: {pb['seconds']:.1f} s, {pb['flop'] / 1e12:.2f} TFLOP -> "
-                      f"{rate / 1e12:.3f} TFLOP/s blended; the step's 10 such pairs are {100 * share:.0f} % of its {FLOP_PER_STEP_CFG:.3e} FLOP; "
-                      f"whole step EXTRAPOLATED at the blended rate: {est_s:.0f} s/step. kind 'port' = oracle/vista_oracle.py (fp32 restatement of the "
-                      "reference, pinned to the reference's own modules by tests/test_oracle_cpu.py)",
+            "sample": f"six full-size pieces of the step timed in this run on the host ({cores} threads) through the ORACLE (oracle/vista_oracle.py: fp32 restatement "
+                      f"of the reference, pinned to the reference's own modules by tests/test_oracle_cpu.py -- not the reference itself, which does not exist on "
+                      f"this box), one 25-frame clip each, network weights: "
+                      + "; ".join(f"{n}: {t:.1f} s, {f / 1e12:.2f} TFLOP" for n, t, f in pieces) +
+                      f" -> {rate / 1e12:.3f} TFLOP/s blended; 2 clips x 5 such pairs per level are {100 * share:.0f} % of the step's {FLOP_PER_STEP_CFG:.3e} FLOP; "
+                      f"the rest is EXTRAPOLATED at the blended rate: {est_s:.0f} s/step",
             "measured": {"seconds": t_meas, "flop": f_meas, "share_of_step_flop": share},
             "parity_rel_l2_hip_vs_oracle": parity}
 
@@ -303,8 +312,6 @@ def main():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        if profile_attn:
-            ops.PROFILE_ATTN = []
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.warmup, args.warmup + args.steps):
@@ -322,13 +329,22 @@ def main():
         # Host cost of enqueueing ONE step, measured OUTSIDE the timed region from an idle stream (sync, enqueue, stop the clock before the
         # next sync): inside the timed region the launch queue is full and the host clock only sees the GPU's back-pressure.
         t_enq = None
-        if args.warmup + args.steps < nsteps:
-            saved, ops.PROFILE_ATTN = ops.PROFILE_ATTN, None  # the attention events belong to the timed region only
+        nxt = args.warmup + args.steps
+        if nxt < nsteps:
             t1 = time.perf_counter()
-            loop.step(args.warmup + args.steps)
+            loop.step(nxt)
             t_enq = time.perf_counter() - t1
             torch.cuda.synchronize()
-            ops.PROFILE_ATTN = saved
+            nxt += 1
+            if dist is not None:
+                dist.barrier()
+        # The roofline kernel's launches are timed with HIP events (recorded on the launch stream, ops.attn_spatial) on up to two MORE steps of
+        # the same window, right after the timed region: the timed region itself carries no profiling work
+        if profile_attn and not graph:
+            ops.PROFILE_ATTN = []
+            for i in range(nxt, min(nxt + 2, nsteps)):
+                loop.step(i)
+            torch.cuda.synchronize()
             if dist is not None:
                 dist.barrier()
         return dt, t_enq, loop
@@ -356,14 +372,28 @@ def main():
         avg_ms = sum(l0) / len(l0)
         flop = 4.0 * nbh * float(H * W) ** 2 * 64
         ach = flop / (avg_ms * 1e-3) / 1e12
-        traffic = None  # HBM bytes per launch from the separate PMC passes (profiles/r04_attn_traffic.json), full config only
-        tp = os.path.join(ROOT, "profiles", "r04_attn_traffic.json")
-        if full and world == 1 and os.path.exists(tp):
-            traffic = json.load(open(tp))["traffic_bytes_per_launch"]
-        roofline = {"kernel": "attn_spatial_kernel (level-0 spatial self-attention)", "bound": "mfma", "achieved": ach,
+        # HBM bytes per launch come from separate rocprofv3 PMC passes (they cannot share a run with the timed region): the newest
+        # profiles/r*_attn_traffic.json, which is STAMPED with the sha256 of the csrc/attention.hip it was measured on -- a kernel source that
+        # has changed since reports no traffic rather than stale bytes
+        traffic, traffic_src = None, "no profiles/r*_attn_traffic.json"
+        if full and world == 1:
+            import glob
+            import hashlib
+            sha = hashlib.sha256(open(os.path.join(ROOT, "vista_amd", "csrc", "attention.hip"), "rb").read()).hexdigest()
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_attn_traffic.json")))
+            if cands:
+                rec = json.load(open(cands[-1]))
+                name = os.path.relpath(cands[-1], ROOT)
+                if rec.get("attention_hip_sha256") == sha:
+                    traffic = rec["traffic_bytes_per_launch"]
+                    traffic_src = f"rocprofv3 PMC passes of the same kernel and shape, {name} (sha256 of csrc/attention.hip matches the loaded tree)"
+                else:
+                    traffic_src = f"{name} was measured on another csrc/attention.hip (sha256 mismatch): traffic dropped, re-run tools/prof_pmc_attn.sh"
+        roofline = {"kernel": "level-0 spatial self-attention (vk_attn_spatial_qkv_log2_bf16)", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": traffic,
-                    "traffic_source": "rocprofv3 PMC passes of the same kernel and shape, profiles/r04_attn_traffic.json (PMC passes cannot share a run with the timed region)",
-                    "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop}
+                    "traffic_source": traffic_src,
+                    "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop,
+                    "timed_on": "HIP events on the launch stream around each level-0 launch of up to two extra steps of the same window, immediately after the timed region"}
 
     def layout(sh):
         return (("CFG-split x2 x " if sh.cfg_half is not None else "") + "frame-sharded " + "/".join(str(c) for c in sh.t_counts)) if sh else "single GPU"

@@ -71,6 +71,12 @@ typedef struct VkGemmDesc {
     void* mx8_out;
     void* mx8_scales;
     int32_t mx8_cols, ld_mx8, ld_mx8s;
+    /* ---- row range (ABI v5): this call computes output rows [m_begin, m_end) of the M-row problem only; 0 / 0 = all rows. Everything else
+     *   (M as the extent of the operands, of the row-sum slabs and of the conv / temporal sources) is unchanged, so a problem may be covered by
+     *   several calls with bitwise the same result as one call. vk_gemm_bf16 uses it itself: when the last round of a one-tile-per-workgroup
+     *   launch would leave most of the chip idle (tiles mod 256 small), the whole rounds run on the 256x320 pipelined kernel and the remaining
+     *   rows as a second launch of 128x160 tiles. EPI_LINEAR / EPI_GEGLU, no split-K. ---- */
+    int32_t m_begin, m_end;
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
@@ -85,6 +91,10 @@ int vk_gemm_rowstat_parts(const VkGemmDesc* d);
 /* The launcher's decision for `desc` without launching anything (host arithmetic only): block-tile variant (1 = 128x128, 2 = 256x128,
  * 3 = 256x256, 4 = 256x320, 5 = 128x160) * 16 + number of K slices; negative = the error vk_gemm_bf16 would return. */
 int vk_gemm_tile_choice(const VkGemmDesc* d);
+/* The output row at which vk_gemm_bf16 would split this problem into two launches (whole rounds of 256x320 tiles on the pipelined kernel +
+ * the remaining rows as 128x160 tiles; VkGemmDesc.m_begin / m_end), 0 = a single launch; negative = the error vk_gemm_bf16 would return.
+ * Pure host function, no launch. */
+int vk_gemm_tail_split(const VkGemmDesc* d);
 
 /* fp8 (OCP e4m3) variant of the DENSE GEMM for the UNet's Linear / 1x1 projections (BASELINE.json config 5: "fp8 1x1
  * conv-as-GEMM path"; same reference call sites as vk_gemm_bf16's DENSE mode: attention.py:268-285,97-128, video_attention.py).

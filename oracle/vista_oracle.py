@@ -303,9 +303,11 @@ def guider_prepare_inputs(x, s, c, cond_mask, uc):
 
 
 def euler_edm_sample(denoise_fn, x, cond, uc, cond_frame, cond_mask, num_steps, scale=2.5, sigma_max=700.0, sigma_min=0.002, rho=7.0,
-                     guider="cfg"):
-    """EulerEDMSampler.__call__ with s_churn=0, sampling.py:30-45,78-124. `denoise_fn(x, sigma, cond, cond_mask)` is
-    the closure of sample_utils.py:314-315. guider: 'cfg' (VanillaCFG-like prepare/combine) or 'identity'."""
+                     guider="cfg", s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, noise_fn=None):
+    """EulerEDMSampler.__call__, sampling.py:30-45,78-124. `denoise_fn(x, sigma, cond, cond_mask)` is the closure of
+    sample_utils.py:314-315. guider: 'cfg' (VanillaCFG-like prepare/combine) or 'identity'. s_churn > 0: the stochastic branch of
+    sampler_step (sampling.py:78-83): gamma = min(s_churn / (n_sigmas - 1), sqrt(2) - 1) while s_tmin <= sigma <= s_tmax (:109-113),
+    sigma_hat = sigma (1 + gamma), x += noise_fn(x) * s_noise * sqrt(sigma_hat^2 - sigma^2); noise_fn defaults to torch.randn_like."""
     x = x.clone()
     sigmas = edm_sigmas(num_steps, sigma_min, sigma_max, rho)
     x *= torch.sqrt(1.0 + sigmas[0] ** 2)
@@ -315,6 +317,12 @@ def euler_edm_sample(denoise_fn, x, cond, uc, cond_frame, cond_mask, num_steps, 
         if replace:
             x = x * append_dims(1 - cond_mask, x.ndim) + cond_frame * append_dims(cond_mask, cond_frame.ndim)
         sigma, next_sigma = s_in * sigmas[i], s_in * sigmas[i + 1]
+        gamma = min(s_churn / (len(sigmas) - 1), 2 ** 0.5 - 1) if s_tmin <= float(sigmas[i]) <= s_tmax else 0.0
+        if gamma > 0:
+            sigma_hat = sigma * (gamma + 1.0)
+            eps = (torch.randn_like(x) if noise_fn is None else noise_fn(x)) * s_noise
+            x = x + eps * append_dims(sigma_hat ** 2 - sigma ** 2, x.ndim) ** 0.5
+            sigma = sigma_hat
         if guider == "identity":
             denoised = denoise_fn(x, sigma, cond, cond_mask)
         else:

@@ -57,3 +57,35 @@ def test_safetensors_round_trip_into_modules(tmp_path):
     assert rep["unet"] == (["out.2.weight"], ["out.2.weightX"])
     with pytest.raises(NotImplementedError):
         checkpoint.load_checkpoint("model.bin")
+
+
+def test_training_dump_of_the_gpu_test_converts_back_to_its_target():
+    """The DeepSpeed-style dump tests/test_checkpoint_gpu.py builds (LoRA on live + EMA families, EMA shadows, bookkeeping scalars) goes back to
+    the target weights through convert_training_checkpoint -- here on the 64-channel network (same names) -- and, where the reference is
+    mounted, through the reference's own bin_to_st.py with identical results."""
+    from tests.test_checkpoint_gpu import training_dump
+    from vista_amd.config import unet_kwargs
+    from vista_amd.modules.diffusionmodules.video_model import VideoUNet
+    net = VideoUNet(**unet_kwargs(64))
+    target = synth.seeded_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, 0)
+    dump, n_lora = training_dump(target)
+    conv = checkpoint.convert_training_checkpoint(dump)
+    parts = checkpoint.split_by_component(conv)
+    assert n_lora == 12 and sorted(parts["unet"]) == sorted(target) and not parts["decoder"] and not parts["rest"]
+    worst = max((parts["unet"][k] - v).abs().max().item() / max(v.abs().max().item(), 1e-12) for k, v in target.items())
+    assert worst <= 1e-6, worst
+    ref = os.path.join(os.environ.get("VISTA_REFERENCE", "/root/reference"), "bin_to_st.py")
+    if os.path.exists(ref):
+        import safetensors.torch as st
+        captured = {}
+        real_load, real_save, real_mk = torch.load, st.save_file, os.makedirs
+        torch.load = lambda *a, **k: {kk: v.clone() for kk, v in dump.items()}
+        st.save_file = lambda d, path: captured.update(d)
+        os.makedirs = lambda *a, **k: None
+        try:
+            import contextlib, io
+            with contextlib.redirect_stdout(io.StringIO()):
+                exec(compile(open(ref).read(), "bin_to_st.py", "exec"), {"__name__": "__main__"})
+        finally:
+            torch.load, st.save_file, os.makedirs = real_load, real_save, real_mk
+        assert sorted(captured) == sorted(conv) and all(torch.equal(captured[k], conv[k]) for k in conv)

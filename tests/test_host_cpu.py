@@ -391,8 +391,16 @@ def test_packable_cache_key_sees_replaced_parameters_and_inference_tensors():
     packables = [x for x in net.modules() if isinstance(x, Packable)]
     for x in packables:
         x._pk = {"stale": True}
+    from vista_amd.modules import attention as att
+    gen0 = att.pack_generation()
     net.load_state_dict(net.state_dict())
     assert all(x._pk is None for x in packables)
+    # 6. ... and moves the pack generation, which the hipGraph cache of the forward keys on (a captured graph holds raw pointers into
+    #    the packs; version counters cannot see p.data writes / inference-tensor loads, invalidate_packed() is the one door they all use)
+    assert att.pack_generation() >= gen0 + len(packables)
+    gen1 = att.pack_generation()
+    att.invalidate_packed(net)
+    assert att.pack_generation() == gen1 + len(packables)
 
 
 def test_config_fallback_equals_shipped_yaml_and_import_is_lazy():
@@ -487,3 +495,40 @@ def test_gemm_launch_rules_are_pinned():
     cfg, ks = choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32)
     assert cfg == 7 and ks >= 2, "small-M deep-K convolutions run split-K on the big tile (its pipelined kernel since round 4)"
     assert choice(r2, 1280, 11520, amode=ops.AMODE_CONV3X3, Cin=1280, H=18, W=32, ws=False) [1] == 1  # no workspace, no split
+
+
+def test_gemm_tail_split_rule_is_pinned():
+    """vk_gemm_tail_split: where vk_gemm_bf16 cuts a one-tile-per-workgroup launch into whole rounds + a 128x160 tail (round 5). Host arithmetic only.
+    Level 0 of the BASELINE window is 460800 rows = 1800 row tiles of 256: 7.03 rounds at N = 320 (tail = the last 8 row tiles), 21.09 at N = 960."""
+    import ctypes as C
+    from vista_amd import _lib, ops
+    lib = _lib.load()
+    one = C.c_void_p(16)
+
+    def split(M, N, K, amode=ops.AMODE_DENSE, stats=False, Cin=0, H=0, W=0, **kw):
+        d = _lib.VkGemmDesc()
+        d.A = d.Wt = d.out = one
+        d.M, d.N, d.K, d.lda, d.ldc = M, N, K, K, N
+        d.amode, d.epi, d.alpha = amode, ops.EPI_LINEAR, 1.0
+        d.splitk_ws, d.splitk_ws_bytes = one, 160 << 20
+        if stats:
+            d.rowstat_out = one
+        if amode == ops.AMODE_CONV3X3:
+            d.Cin, d.H, d.Wd, d.Hout, d.Wout, d.stride, d.ups = Cin, H, W, H, W, 1, 1
+        if amode == ops.AMODE_TEMPORAL3:
+            d.Cin, d.T, d.S = Cin, 25, H * W
+        for k, v in kw.items():
+            setattr(d, k, v)
+        return lib.vk_gemm_tail_split(C.byref(d))
+
+    full, L1, L2 = 50 * 9216, 50 * 2304, 50 * 576
+    assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128) == 1792 * 256       # 7 full rounds, then 8 row tiles
+    assert split(full, 320, 960, amode=ops.AMODE_TEMPORAL3, Cin=320, H=72, W=128) == 1792 * 256
+    assert split(full, 960, 320) == 1792 * 256                                                         # q|k|v: 5400 tiles = 21 rounds + 24
+    assert split(full, 320, 1280, stats=True) == 1792 * 256
+    assert split(full, 320, 320, stats=True) == 0                                                      # 128x160 tiles already (cfg 5)
+    assert split(L1, 640, 5760, amode=ops.AMODE_CONV3X3, Cin=640, H=36, W=64) == 0                     # 900 tiles = 3.52 rounds: the tail is half a round
+    assert split(L2, 1280, 1280, stats=True) == 0                                                      # 452 tiles = 1.77 rounds
+    assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, tile_cfg=7) == 0      # a forced variant is never split
+    assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, m_begin=256, m_end=full) == 256 + 1792 * 256   # 1799 tiles of a row range: 7 rounds + 7
+    assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, m_begin=5, m_end=4) < 0      # bad range

@@ -656,6 +656,88 @@ def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
     assert torch.equal(o7, o4), "pipelined and sixteen-wave kernels must agree bit for bit"
 
 
+@pytest.mark.parametrize("kind", ["qkv_lnfold", "dense_K4N+res+stats", "conv3x3+emb+res", "conv_t3+blend"])
+@pytest.mark.parametrize("n,H,W", [(29, 36, 64), (30, 35, 64)])   # 261 row tiles of 256 (5 in the last round); 262.5 (ragged last tile)
+def test_gemm_tail_split_and_row_ranges_are_bitwise(kind, n, H, W):
+    """Round 5: a one-tile-per-workgroup launch of the pipelined 256x320 kernel whose last round would be nearly empty is split by vk_gemm_bf16
+    into whole rounds on that kernel + the remaining rows as 128x160 tiles (VkGemmDesc.m_begin / m_end; vk_gemm_tail_split names the row).
+    Every output element sees the same MFMA sequence and the row-sum slabs are the same 160-column blocks, so (a) the launcher's own (split)
+    launch, (b) the forced single launch (tile_cfg 7 disables the split) and (c) three explicit row-range calls that together cover the rows
+    must agree BIT FOR BIT -- outputs and row sums -- and match torch fp32. Reference call sites as test_gemm_pipe_is_bitwise_..."""
+    import ctypes as C
+    from vista_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    Cc, S = 320, H * W
+    M = n * S
+    x = rnd(M, Cc)
+    x3 = x.view(n, S, Cc)
+    res = rnd(M, Cc, seed=3)
+    rv = rnd(n, Cc, seed=5).float()
+    if kind == "qkv_lnfold":
+        nrm = _Norm(Cc, 7)
+        w, b = rnd(3 * Cc, Cc, scale=Cc ** -0.5, seed=1), rnd(3 * Cc, seed=2).float()
+        pw = ops.pack_linear(w, b, ln=nrm)
+        st = ops.rowstats(x)
+        fn = lambda **kw: ops.linear(x, pw, ln=st, **kw)  # noqa: E731
+        ref = _ln_ref(x, nrm.weight, nrm.bias) @ w.float().t() + b
+        N = 3 * Cc
+    elif kind == "dense_K4N+res+stats":
+        h4 = rnd(M, 4 * Cc, seed=9)
+        w, b = rnd(Cc, 4 * Cc, scale=(4 * Cc) ** -0.5, seed=1), rnd(Cc, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda **kw: ops.linear(h4, pw, res1=res, rowvec=rv, rows_per_vec=S, **kw)  # noqa: E731
+        ref = h4.float() @ w.float().t() + b + res.float() + rv.repeat_interleave(S, 0)
+        N = Cc
+    elif kind == "conv3x3+emb+res":
+        w, b = rnd(Cc, Cc, 3, 3, scale=(9 * Cc) ** -0.5, seed=1), rnd(Cc, seed=2).float()
+        pw = ops.pack_conv3x3(w, b)
+        fn = lambda **kw: ops.conv3x3(x3, pw, n, H, W, rowvec=rv, res1=x3, **kw)[0]  # noqa: E731
+        ref = (_nchw2tok(F.conv2d(_tok2nchw(x3, n, H, W), w.float(), b, padding=1)) + rv[:, None, :] + x3.float()).reshape(M, Cc)
+        N = Cc
+    else:
+        w, b = rnd(Cc, Cc, 3, 1, 1, scale=(3 * Cc) ** -0.5, seed=1), rnd(Cc, seed=2).float()
+        pw = ops.pack_conv_t3(w, b)
+        x5 = x3.float().view(1, n, S, 1, Cc).permute(0, 4, 1, 2, 3)
+        ref = (0.3 * F.conv3d(x5, w.float(), b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(n, S, Cc) + x3.float()).reshape(M, Cc)
+        fn = lambda **kw: ops.conv_t3(x3, pw, n, S, res2=x3, alpha=0.3, beta=1.0, **kw)  # noqa: E731
+        N = Cc
+    stats = kind == "dense_K4N+res+stats"
+    auto = fn(emit_stats=True) if stats else fn()
+    ops.TILE_CFG = 7
+    try:
+        single = fn(emit_stats=True) if stats else fn()
+    finally:
+        ops.TILE_CFG = 0
+    if stats:
+        (auto, sa), (single, ss) = auto, single
+        assert sa.parts == ss.parts and torch.equal(sa.t, ss.t), "row-sum slabs of the split launch differ from the single launch"
+        _check_stats(sa, auto)
+    close(auto.reshape(M, N), ref, f"tail split {kind}")
+    assert torch.equal(auto, single), "split and single launches must agree bit for bit"
+    # the launcher did split (host query), at a whole number of full rounds
+    tiles_n, tiles_m = N // 320, (M + 255) // 256
+    full = tiles_m * tiles_n // 256
+    assert full >= 1 and 0 < tiles_m * tiles_n % 256 <= 0.4 * 256
+    # (c) explicit row ranges: [0, a) on whatever the launcher picks, [a, b) and [b, M) likewise, written into one output
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    a, b_ = 256 * 100 + 64, M - 300   # deliberately not tile aligned
+    for lo, hi in ((0, a), (a, b_), (b_, M)):
+        ops.ROW_RANGE = (lo, hi)
+        try:
+            fn(out=out)
+        finally:
+            ops.ROW_RANGE = None
+    assert torch.equal(out.reshape(-1), single.reshape(-1)), "row-range calls must reproduce the single launch bit for bit"
+    # an invalid range is refused
+    ops.ROW_RANGE = (M, M)
+    try:
+        with pytest.raises(Exception):
+            fn()
+    finally:
+        ops.ROW_RANGE = None
+
+
 def test_gemm_pipe_is_what_the_launcher_runs_and_refusals():
     """The launcher's own choice (vk_gemm_tile_choice) is the pipelined kernel wherever the 256x320 tile is, its split-K form and the fused
     nearest-x2 upsample included; what it does not take (halo frames of a frame-sharded run, fp32 output, two-source A) stays on the sixteen-wave

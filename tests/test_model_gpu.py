@@ -166,6 +166,34 @@ def test_sampler_and_denoiser_vs_reference_golden():
     assert r <= 2.5e-2
 
 
+def test_stochastic_sampler_step_vs_reference_golden():
+    """The gamma > 0 branch of EulerEDMSampler.sampler_step (reference sampling.py:78-83: sigma_hat = sigma (1 + gamma), x += eps * s_noise *
+    sqrt(sigma_hat^2 - sigma^2)), which Vista's configs leave off but the sampler API carries: 4 steps, s_churn 1.2 (gamma 0.3) inside
+    [s_tmin 0.05, s_tmax 400] -> steps 1 and 2 churn, 0 and 3 do not. The noise the REFERENCE drew (recorded by oracle/make_golden_churn.py) is
+    injected through the sampler's `noise_fn` hook; the FusedDenoiser is passed, so this also checks that s_churn > 0 leaves the fused path."""
+    from vista_amd import synth
+    from vista_amd.modules.diffusionmodules.denoiser import Denoiser
+    from vista_amd.modules.diffusionmodules.sampling import EulerEDMSampler, FusedDenoiser
+    from vista_amd.modules.diffusionmodules.wrappers import OpenAIWrapper
+    g = torch.load(os.path.join(GOLD, "sampler_churn_tiny.pt"))
+    net, _ = tiny_unet()
+    T, H, W, prm = g["T"], g["H"], g["W"], g["params"]
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1, trajectory=TRAJ)
+    den = Denoiser(scaling_config={"target": "vwm.modules.diffusionmodules.denoiser_scaling.VScalingWithEDMcNoise"}, num_frames=T)
+    cu = lambda d: {k: v.cuda() for k, v in d.items()}  # noqa: E731
+    P = "vwm.modules.diffusionmodules."
+    s = EulerEDMSampler(discretization_config={"target": P + "discretizer.EDMDiscretization", "params": {"sigma_min": 0.002, "sigma_max": 700.0, "rho": 7.0}},
+                        guider_config={"target": P + "guiders.VanillaCFG", "params": {"scale": 2.5}}, verbose=False, device="cuda", **prm)
+    draws = iter(d.float() for d in g["draws"])
+    s.noise_fn = lambda x: next(draws)
+    out = s(FusedDenoiser(den, OpenAIWrapper(net)), w["noise"].clone().cuda(), cond=cu(w["c"]), uc=cu(w["uc"]),
+            cond_frame=w["cond_frame"].cuda(), cond_mask=w["cond_mask"].cuda()).cpu()
+    assert next(draws, None) is None, "the sampler did not draw noise on exactly the steps the reference did"
+    r = rel_l2(out, g["out"])
+    print(f"[parity] stochastic sampler (s_churn {prm['s_churn']}, 4 steps, injected reference draws): rel-L2 {r:.4e}")
+    assert torch.isfinite(out).all() and r <= 4e-2 and torch.equal(out[0], w["cond_frame"][0])
+
+
 def test_config1_miniature_25_frames_10_steps_vs_reference_golden():
     """BASELINE config 1 in miniature: 1 cond frame -> 25 frames, 10 EDM steps, VanillaCFG 2.5, against the real reference sampler's
     output (CPU fp32, stored fp16). Ten Euler steps compound the per-step bf16 error; tolerance rel-L2 <= 6e-2."""

@@ -57,6 +57,25 @@ def test_oracle_unet_matches_reference_golden(tag):
     assert _rel(out, g["out"]) < 2e-4
 
 
+def test_oracle_stochastic_sampler_step_matches_reference_golden():
+    """The gamma > 0 branch of sampler_step (sampling.py:78-83) with the reference's own recorded noise draws injected
+    (oracle/make_golden_churn.py): two of the four steps lie inside [s_tmin, s_tmax] and churn."""
+    g = torch.load(os.path.join(GOLD, "sampler_churn_tiny.pt"))
+    sd, _ = _tiny_sd()
+    T, H, W, prm = g["T"], g["H"], g["W"], g["params"]
+    w = synth.window_inputs(T=T, H=H, W=W, seed=g["seed_x"], n_cond=1, trajectory=[0.5, 0, 1.0, 0, 1.5, 0.1, 2.0, 0.2])
+    draws = iter(d.float() for d in g["draws"])
+    with torch.no_grad():
+        out = O.euler_edm_sample(lambda x, sigma, cond, m: O.denoiser_forward(sd, x, sigma, cond, m, T), w["noise"], w["c"], w["uc"], w["cond_frame"],
+                                 w["cond_mask"], prm["num_steps"], scale=2.5, s_churn=prm["s_churn"], s_tmin=prm["s_tmin"], s_tmax=prm["s_tmax"],
+                                 s_noise=prm["s_noise"], noise_fn=lambda x: next(draws))
+        assert next(draws, None) is None, "not every recorded draw was consumed"
+        assert _rel(out, g["out"]) < 5e-4
+        plain = O.euler_edm_sample(lambda x, sigma, cond, m: O.denoiser_forward(sd, x, sigma, cond, m, T), w["noise"], w["c"], w["uc"],
+                                   w["cond_frame"], w["cond_mask"], prm["num_steps"], scale=2.5)
+    assert _rel(plain, g["out"]) > 5e-2, "the churn must matter for the fixture to test anything"
+
+
 def test_oracle_sampler_matches_reference_golden():
     g = torch.load(os.path.join(GOLD, "sampler_tiny.pt"))
     sd, _ = _tiny_sd()

@@ -35,10 +35,11 @@ class VkGemmDesc(C.Structure):
         ("ln_parts", _i32), ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_eps", _f32),
         ("rowstat_out", _vp), ("rowvec2", _vp), ("act", _i32),
         ("mx8_out", _vp), ("mx8_scales", _vp), ("mx8_cols", _i32), ("ld_mx8", _i32), ("ld_mx8s", _i32),
+        ("m_begin", _i32), ("m_end", _i32),
     ]
 
 
-ABI_VERSION = 4  # vk_abi_version() of the library this table mirrors
+ABI_VERSION = 5  # vk_abi_version() of the library this table mirrors
 
 # name -> argtypes; every entry returns int. Must list every symbol include/vista_hip.h declares
 # (tests/test_abi.py checks the header against this table and against the built library).
@@ -46,6 +47,7 @@ SIGNATURES = {
     "vk_gemm_bf16": [C.POINTER(VkGemmDesc), _vp],
     "vk_gemm_rowstat_parts": [C.POINTER(VkGemmDesc)],
     "vk_gemm_tile_choice": [C.POINTER(VkGemmDesc)],
+    "vk_gemm_tail_split": [C.POINTER(VkGemmDesc)],
     "vk_gemm_fp8": [C.POINTER(VkGemmDesc), _vp, _vp, _i32, _vp],
     "vk_gemm_fp8_mx": [C.POINTER(VkGemmDesc), C.POINTER(VkFp8Args), _vp],
     "vk_gemm_fp8_rowstat_parts": [C.POINTER(VkGemmDesc)],

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
         }
         __syncthreads();
 
-        // the out-projection epilogue's per-column / per-image vectors overlay W1 slot 0 (dead by then); block-uniform plan
+        // the out-projection epilogue's per-column / per-image vectors overlay the W2 ring (dead by then); block-uniform plan
         float* const epi_vec = (float*)(smem + OFF_W2);
         const EpiPlan eplan = epi_plan<EPI_LINEAR, false, FF_BM, FF_C>(p2, m0, 0);
         f32x16_t E[5][1];   // the wave's share of the output tile in the epilogue: 32 tokens x 160 columns
@@ -385,13 +385,22 @@ extern "C" int vk_ff_fused_bf16(const VkGemmDesc* geglu, const VkGemmDesc* out_p
     if (rc != VK_OK) return rc;
     const int ntiles = (geglu->M + FF_BM - 1) / FF_BM;
     const int grid = ntiles < 256 ? ntiles : 256;  // persistent: one workgroup per CU (141 KB of LDS) walks the tile list
-    switch (geglu->tile_cfg) {  // (0 in the product; the timing experiments of tools/ff_fused_probe.py set 1 / 2 / 4)
+    VkGemmDesc g1 = *geglu, o1 = *out_proj;       // the shared epilogues bound their rows by m_end (ABI v5 row ranges: not offered here, all rows)
+    g1.m_begin = o1.m_begin = 0;
+    g1.m_end = o1.m_end = geglu->M;
+    geglu = &g1;
+    out_proj = &o1;
+#ifdef FF_TIMING   // tuning builds only (tools/ff_fused_probe.py): geglu->tile_cfg selects a timing variant; 1 / 2 / 4 give WRONG results by design
+    switch (geglu->tile_cfg) {
         case 1: hipLaunchKernelGGL(ff_fused_kernel<1>, dim3(grid), dim3(FF_NT), 0, (hipStream_t)stream_, *geglu, *out_proj); break;
         case 2: hipLaunchKernelGGL(ff_fused_kernel<2>, dim3(grid), dim3(FF_NT), 0, (hipStream_t)stream_, *geglu, *out_proj); break;
         case 8: hipLaunchKernelGGL(ff_fused_kernel<8>, dim3(grid), dim3(FF_NT), 0, (hipStream_t)stream_, *geglu, *out_proj); break;
         case 4: hipLaunchKernelGGL(ff_fused_kernel<4>, dim3(grid), dim3(FF_NT), 0, (hipStream_t)stream_, *geglu, *out_proj); break;
         default: hipLaunchKernelGGL(ff_fused_kernel<0>, dim3(grid), dim3(FF_NT), 0, (hipStream_t)stream_, *geglu, *out_proj);
     }
+#else   // the product library carries ONE instantiation; tile_cfg (vk_gemm_bf16's tile-variant selector) has no meaning here and is ignored
+    hipLaunchKernelGGL(ff_fused_kernel<0>, dim3(grid), dim3(FF_NT), 0, (hipStream_t)stream_, *geglu, *out_proj);
+#endif
     VK_CHECK_LAUNCH();
     return VK_OK;
 }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES + BM * 8 + epi_vec_floats(BN) * 4];
 
     const int tilesN = (p.N + BN - 1) / BN;
-    const int tilesM = (p.M + BM - 1) / BM;
+    const int tilesM = (p.m_end - p.m_begin + BM - 1) / BM;   // row tiles of this launch's row range [m_begin, m_end) (launchers normalise m_end)
     // split-K (small-M problems): workgroup = (K slice, tile), K slice as the slow index so neighbours still share weight tiles
     const int ntiles = tilesM * tilesN;
     // PERSIST (GEGLU kernels): a launch of 256 workgroups walks the tile list with stride gridDim.x instead of one workgroup per tile: no
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         tm = panel * GM + r % gm;
         tn = r / gm;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = p.m_begin + tm * BM, n0 = tn * BN;
 
     const uint16_t* __restrict__ Ag = (const uint16_t*)p.A;
     const uint16_t* __restrict__ Wg = (const uint16_t*)p.Wt;
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         int m = m0 + lr + RPP * i;
-        a_ok[i] = m < p.M;
-        if (m >= p.M) m = p.M - 1;
+        a_ok[i] = m < p.m_end;
+        if (m >= p.m_end) m = p.m_end - 1;
         if (AMODE == AMODE_DENSE) {
             aptr[i] = Ag + (size_t)m * p.lda + lsrc * 8;
             a_y0[i] = m;  // row index, for the second source of a channel-concatenated A
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         // flight together; visible to every wave after the barrier below.
         for (int r = tid; r < BM; r += NT) {
             const int m = m0 + r;
-            lnrow_cur[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
+            lnrow_cur[r] = ln_row_stats(p, m < p.m_end ? m : p.m_end - 1);
         }
     }
     __syncthreads();
@@ -414,7 +414,7 @@ template <int AMODE, int EPI, bool OUT_F32, int WM, int WN, int FM, int FN>
 int launch_cfg(const VkGemmDesc* d, hipStream_t stream, int ksplit = 1) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tilesN = (d->N + BN - 1) / BN;
-    const int tilesM = (d->M + BM - 1) / BM;
+    const int tilesM = (d->m_end - d->m_begin + BM - 1) / BM;   // (vk_gemm_bf16 normalised the row range)
     VkGemmDesc desc = *d;
     // Activation rows that at most 4 column-tiles ever read are streamed with the non-temporal policy: they would only evict the
     // weight tile every workgroup shares (measured +6-8 % on the K=320 level-0 projections, -5-11 % when 10+ column tiles re-read A).
@@ -453,7 +453,8 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     if (cfg == 7 && !vk_gemm_pipe_fit(d)) cfg = 4;
     if (cfg == 4 && amode == AMODE_CONV3D) cfg = 3;  // the 27-tap loader's extra address state does not fit the 256x320 register budget
     if (cfg == 0) {
-        auto wgs = [&](int bm, int bn) { return (long long)((d->M + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
+        const int rows = d->m_end - d->m_begin;   // (the row range of this call: all M rows unless a caller asked for a part)
+        auto wgs = [&](int bm, int bn) { return (long long)((rows + bm - 1) / bm) * ((d->N + bn - 1) / bn); };
         const int n256 = (d->N + 255) / 256 * 256;
         // GEGLU could run on the 256x320 tile since the fragment-local packing, but measured 2-9 % slower there than on 256x256
         const bool ok320 = (epi != EPI_GEGLU) && (amode != AMODE_CONV3D) && (d->N % 320 == 0);
@@ -497,10 +498,11 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     // tiles x slices ~ one full round of CUs; fp32 partials go to the caller's workspace and a finishing pass applies the epilogue.
     // Not combined with the LayerNorm fold / row-sum emission (their epilogues need the finished accumulator in registers).
     int ksplit = 1;
-    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && cfg != 5 && !d->ln_stats && !d->rowstat_out && !d->act) {
+    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && cfg != 5 && !d->ln_stats && !d->rowstat_out && !d->act &&
+        d->m_begin == 0 && d->m_end == d->M) {   // (the finishing pass walks all M rows: no split-K on a row range)
         const bool ok320s = (amode != AMODE_CONV3D) && (d->N % 320 == 0);
         const int bn = ok320s ? 320 : 256;
-        const long long tiles = (long long)((d->M + 255) / 256) * ((d->N + bn - 1) / bn);
+        const long long tiles = (long long)((d->m_end - d->m_begin + 255) / 256) * ((d->N + bn - 1) / bn);
         const int nk = d->K / BK;
         int s = (int)(256 / tiles);
         if (s > 8) s = 8;
@@ -530,9 +532,41 @@ inline void tile_geometry(int cfg, int& bn, int& wn) {
     else { bn = 128; wn = 2; }
 }
 
+// Tail split of a one-tile-per-workgroup launch of the 256x320 pipelined kernel (LINEAR epilogue). With one 162 KB workgroup per CU the launch
+// takes ceil(tiles / 256) tile times, and the BASELINE shapes leave the last round almost empty: level 0 is 460800 rows = 1800 row tiles =
+// 7.03 rounds at N = 320 (eight tiles keep the chip for an eighth round: 12 % of the launch) and 21.09 at N = 960. When the last round would
+// be filled to at most VISTA_GEMM_TAIL percent, the whole rounds run as rows [m_begin, m_split) on the pipelined kernel and the remaining
+// rows [m_split, m_end) as a second launch of 128x160 tiles (four waves, two workgroups per CU: a quarter of the work per workgroup, all of
+// them resident at once) -- the same MFMA sequence per output element, the same row-sum slabs (160 columns each): bitwise the same result
+// as the single launch (tests/test_kernels_gpu.py::test_gemm_tail_split_is_bitwise). Returns the split row, 0 = no split.
+inline int tail_split_row(const VkGemmDesc* d, const TileChoice& t) {
+    static const int max_pct = [] { const char* e = getenv("VISTA_GEMM_TAIL"); return e ? atoi(e) : 40; }();
+    if (max_pct <= 0 || t.cfg != 7 || t.ksplit != 1 || (d->tile_cfg & 7) != 0 || d->epi != EPI_LINEAR || d->out_f32 || (d->N % 320) != 0) return 0;
+    const int rows = d->m_end - d->m_begin;
+    const long long tilesN = d->N / 320, tilesM = (rows + 255) / 256, ntiles = tilesM * tilesN;
+    const long long full = ntiles / 256, rem = ntiles % 256;
+    if (full == 0 || rem == 0 || rem * 100 > (long long)max_pct * 256) return 0;
+    const long long tm_main = full * 256 / tilesN;   // whole row tiles the full rounds cover
+    if (tm_main <= 0 || tm_main >= tilesM) return 0;
+    const int m_split = d->m_begin + (int)tm_main * 256;
+    const long long small = (long long)((d->m_end - m_split + 127) / 128) * (d->N / 160);
+    if (small > 512) return 0;   // more than one round of the two-per-CU tiles: the tail would no longer be a single short round
+    return m_split;
+}
+
 template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
     const TileChoice t = choose_tile(d);
+    if constexpr (EPI == EPI_LINEAR && !OUT_F32 && (AMODE == AMODE_DENSE || AMODE == AMODE_CONV3X3 || AMODE == AMODE_TEMPORAL3)) {
+        if (const int m_split = tail_split_row(d, t)) {
+            VkGemmDesc head = *d, tail = *d;
+            head.m_end = m_split;
+            tail.m_begin = m_split;
+            const int rc = vk_gemm_pipe_launch(&head, stream, 1);
+            if (rc != VK_OK) return rc;
+            return launch_cfg<AMODE, EPI, OUT_F32, 4, 1, 1, 5>(&tail, stream);
+        }
+    }
     if constexpr (AMODE == AMODE_DENSE && EPI == EPI_LINEAR && !OUT_F32) {
         if (t.cfg == 5) return launch_cfg<AMODE, EPI, OUT_F32, 4, 1, 1, 5>(d, stream);  // 128x160: four 32x160 wave tiles, two workgroups per CU
     }
@@ -560,6 +594,8 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 inline int validate(const VkGemmDesc* d) {
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || d->tile_cfg > 7) return VK_EINVAL;
+    if (d->m_begin < 0 || d->m_end < 0 || d->m_end > d->M || (d->m_end != 0 && d->m_begin >= d->m_end) || (d->m_end == 0 && d->m_begin >= d->M)) return VK_EINVAL;
+    if ((d->m_begin != 0 || (d->m_end != 0 && d->m_end != d->M)) && d->epi == EPI_TRANS) return VK_EINVAL;   // (row ranges: LINEAR / GEGLU)
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
     if (d->amode == AMODE_DENSE && (d->lda % 8) != 0) return VK_EINVAL;
     if (d->amode == AMODE_CONV3X3 && (d->K != 9 * d->Cin || d->stride < 1 || d->stride > 2 || d->ups < 1 || d->ups > 2)) return VK_EINVAL;
@@ -596,9 +632,10 @@ extern "C" int vk_gemm_rowstat_parts(const VkGemmDesc* d) {
     if (rc != VK_OK) return rc;
     if (d->epi != EPI_LINEAR || d->out_f32) return VK_EINVAL;
     VkGemmDesc q = *d;
+    norm_row_range(q);
     q.rowstat_out = (float*)1;  // what the launcher will see (callers size the buffer from this answer BEFORE they can set the pointer): the
                                 // streaming kernel is not chosen on its own for a row-sum emitting launch, and such a launch is never split-K
-    if (const int fit = stream_fit(&q)) return d->N / (32 * fit);  // one slab per column tile: the workgroup combines its waves' row sums
+    if (const int fit = (q.m_begin == 0 && q.m_end == q.M) ? stream_fit(&q) : 0) return d->N / (32 * fit);  // one slab per column tile: the workgroup combines its waves' row sums
     if ((q.tile_cfg & 7) == 6) q.tile_cfg &= ~7;
     const TileChoice t = choose_tile(&q);
     int bn, wn;
@@ -611,19 +648,34 @@ extern "C" int vk_gemm_rowstat_parts(const VkGemmDesc* d) {
 extern "C" int vk_gemm_tile_choice(const VkGemmDesc* d) {
     const int rc = validate(d);
     if (rc != VK_OK) return rc;
-    if (stream_fit(d)) return 6 * 16 + 1;
     VkGemmDesc q = *d;
+    norm_row_range(q);
+    if (q.m_begin == 0 && q.m_end == q.M && stream_fit(d)) return 6 * 16 + 1;
     if ((q.tile_cfg & 7) == 6) q.tile_cfg &= ~7;
     const TileChoice t = choose_tile(&q);
     return t.cfg * 16 + t.ksplit;
+}
+
+// The row at which vk_gemm_bf16 would split `d` into a pipelined launch of whole rounds + a 128x160 tail launch (tail_split_row), 0 = one launch;
+// negative = the error vk_gemm_bf16 would return. Pure host arithmetic.
+extern "C" int vk_gemm_tail_split(const VkGemmDesc* d) {
+    const int rc = validate(d);
+    if (rc != VK_OK) return rc;
+    VkGemmDesc q = *d;
+    norm_row_range(q);
+    if (q.m_begin == 0 && q.m_end == q.M && stream_fit(d)) return 0;
+    if ((q.tile_cfg & 7) == 6) q.tile_cfg &= ~7;
+    if (q.epi != EPI_LINEAR || q.out_f32 || q.amode == AMODE_CONV3D) return 0;
+    return tail_split_row(&q, choose_tile(&q));
 }
 
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d_in, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int rc = validate(d_in);
     if (rc != VK_OK) return rc;
-    if (stream_fit(d_in)) return vk_gemm_stream_launch(d_in, stream_);
     VkGemmDesc dq = *d_in;
+    norm_row_range(dq);   // m_end = M unless the caller asked for a row range (validate() checked it)
+    if (dq.m_begin == 0 && dq.m_end == dq.M && stream_fit(d_in)) return vk_gemm_stream_launch(&dq, stream_);
     if ((dq.tile_cfg & 7) == 6) dq.tile_cfg &= ~7;   // streaming variant requested for a problem it does not take: the launcher's own choice
     const VkGemmDesc* d = &dq;
     const bool f32 = d->out_f32 != 0;

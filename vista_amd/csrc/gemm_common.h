@@ -11,6 +11,13 @@ enum { EPI_LINEAR = 0, EPI_GEGLU = 1, EPI_TRANS = 2 };
 
 constexpr int BK = 64;
 
+// Row range of a launch (VkGemmDesc.m_begin / m_end, ABI v5): every launcher passes its kernels a desc whose m_end is the exclusive row bound
+// (0 -> M). false = an invalid range.
+inline bool norm_row_range(VkGemmDesc& d) {
+    if (d.m_end == 0) d.m_end = d.M;
+    return d.m_begin >= 0 && d.m_begin < d.m_end && d.m_end <= d.M;
+}
+
 
 // Fused epilogue shared by the GEMM kernels. Accumulator element r = 4*g + e of tile (fi,fj): X-row = 32*fi + 8*g + 4*lh + e,
 // Y-row = 32*fj + l31 (X = weights / Y = activations, swapped for EPI_TRANS). MW/NW = wave-tile extents along m / n.
@@ -104,7 +111,7 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
 #pragma unroll
         for (int fj = 0; fj < FY; ++fj) {
             const int m = m0 + wm * MW + fj * 32 + l31;
-            if (m >= p.M) continue;  // both lanes of a row (l31, l31 + 32) leave together
+            if (m >= p.m_end) continue;  // both lanes of a row (l31, l31 + 32) leave together (m_end: the launch's row bound, = M unless a row range was asked for)
             const float* rv = rowvec ? rowvec + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
             const float* rv2 = rowvec2 ? rowvec2 + (size_t)(m / p.rows_per_vec) * p.ldv : nullptr;
             float nrm = 0.f, rs = 1.f;
@@ -222,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
 #pragma unroll
         for (int fj = 0; fj < FY; ++fj) {
             const int m = m0 + wm * MW + fj * 32 + l31;
-            if (m >= p.M) continue;
+            if (m >= p.m_end) continue;
             float nrm = 0.f, rs = 1.f;
             if (lnrow) { const float2 t = lnrow[m - m0]; rs = t.y; nrm = -t.x * t.y; }
 #pragma unroll
@@ -350,7 +357,7 @@ __device__ __forceinline__ EpiPlan epi_plan(const VkGemmDesc& p, int m0, int n0)
     if (p.res2 && ((p.ld_res2 % 8) != 0 || (((size_t)p.res2) & 15) != 0)) return e;
     if (p.rowvec || p.rowvec2) {
         if ((p.ldv % 4) != 0 || (p.rowvec && (((size_t)p.rowvec) & 15) != 0) || (p.rowvec2 && (((size_t)p.rowvec2) & 15) != 0)) return e;
-        const int last = (m0 + BM < p.M ? m0 + BM : p.M) - 1;
+        const int last = (m0 + BM < p.m_end ? m0 + BM : p.m_end) - 1;
         e.img0 = m0 / p.rows_per_vec;
         e.nimg = last / p.rows_per_vec - e.img0 + 1;
         if (e.nimg > EPI_NI) return e;
@@ -429,8 +436,8 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
 #pragma unroll
     for (int fj = 0; fj < FY; ++fj) {
         const int m = m0 + wm * MW + fj * 32 + l31;
-        row_ok[fj] = m < p.M;
-        mrow[fj] = row_ok[fj] ? m : p.M - 1;  // loads of a row past M read the last row; only the stores are predicated
+        row_ok[fj] = m < p.m_end;
+        mrow[fj] = row_ok[fj] ? m : p.m_end - 1;  // loads of a row past M read the last row; only the stores are predicated
         if (NRES >= 1) rao[fj] = ((uint32_t)mrow[fj] * (uint32_t)lda_ + (uint32_t)wide_off) * 2u;
         if (NRES == 2) rbo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ld_res2 + (uint32_t)wide_off) * 2u;
         oo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ldc + (uint32_t)(wide_off - (p.mx8_out ? p.mx8_cols : 0))) * 2u;  // (MX tiles never use it)
@@ -563,8 +570,8 @@ __device__ __forceinline__ void gemm_epilogue_geglu_lds(const VkGemmDesc& p, f32
 #pragma unroll
     for (int fj = 0; fj < FY; ++fj) {
         const int m = m0 + wm * MW + fj * 32 + l31;
-        const bool row_ok = m < p.M;
-        const int mc = row_ok ? m : p.M - 1;
+        const bool row_ok = m < p.m_end;
+        const int mc = row_ok ? m : p.m_end - 1;
         float nrm = 0.f, rs = 1.f;
         if (has_ln) { const float2 t = lnrow[mc - m0]; rs = t.y; nrm = -t.x * t.y; }
         uint16_t* op = (uint16_t*)p.out + (size_t)mc * p.ldc + ((n0 + wn * NW) >> 1) + 8 * lh;

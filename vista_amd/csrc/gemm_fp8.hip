@@ -343,7 +343,10 @@ template <int AMODE, int EPI, bool OUT_F32, bool AMX, int WM, int WN, int FM, in
 int launch_cfg(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
     constexpr int BM = WM * FM * 32, BN = WN * FN * 32;
     const int tiles = ((d->N + BN - 1) / BN) * ((d->M + BM - 1) / BM);
-    hipLaunchKernelGGL((gemm_fp8_kernel<AMODE, EPI, OUT_F32, AMX, WM, WN, FM, FN>), dim3(tiles), dim3(WM * WN * 64), 0, stream, *d, q);
+    VkGemmDesc desc = *d;   // the shared epilogues (gemm_common.h) bound their rows by m_end (ABI v5 row ranges: not offered by the fp8 GEMM, all rows)
+    desc.m_begin = 0;
+    desc.m_end = d->M;
+    hipLaunchKernelGGL((gemm_fp8_kernel<AMODE, EPI, OUT_F32, AMX, WM, WN, FM, FN>), dim3(tiles), dim3(WM * WN * 64), 0, stream, desc, q);
     VK_CHECK_LAUNCH();
     return VK_OK;
 }

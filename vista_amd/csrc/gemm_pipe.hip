@@ -51,7 +51,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
 #endif
 
     const int tilesN = p.N / PBN;
-    const int tilesM = (p.M + PBM - 1) / PBM;
+    const int tilesM = (p.m_end - p.m_begin + PBM - 1) / PBM;   // row tiles of this launch's row range [m_begin, m_end)
     const int ntiles = tilesM * tilesN;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.Wt + (size_t)n0 * p.K), 0, (int)((unsigned)PBN * (unsigned)p.K * 2u), 0x00020000);
         amask = 0;
         if (AMODE == AMODE_DENSE) {
-            const int rows = (p.M - m0 < PBM) ? p.M - m0 : PBM;
+            const int rows = (p.m_end - m0 < PBM) ? p.m_end - m0 : PBM;
             ra = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.A + (size_t)m0 * p.lda), 0,
                                                    (int)(((unsigned)(rows - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u), 0x00020000);
             voff_a[0] = ((unsigned)lr * (unsigned)p.lda + (unsigned)lsrc * 8u) * 2u;
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
                 unsigned mk = 0;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    if (m < p.M && y0 + t >= 0 && y0 + t < (p.H << sh)) mk |= 1u << t;
+                    if (m < p.m_end && y0 + t >= 0 && y0 + t < (p.H << sh)) mk |= 1u << t;
                     if (x0 + t >= 0 && x0 + t < (p.Wd << sh)) mk |= 8u << t;
                 }
                 amask |= mk << (6 * i);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             for (int i = 0; i < PAP; ++i) {
                 const int m = m0 + lr + PRPP * i;
                 const int t = (m / p.S) % p.T;
-                if (m < p.M) amask |= ((t > 0 ? 1u : 0u) | 2u | (t + 1 < p.T ? 4u : 0u)) << (3 * i);
+                if (m < p.m_end) amask |= ((t > 0 ? 1u : 0u) | 2u | (t + 1 < p.T ? 4u : 0u)) << (3 * i);
             }
         }
     };
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
     auto plan_of = [&](const int m0) __attribute__((always_inline)) {
         EpiPlan e{true, 0, 1};
         if (EPI == EPI_LINEAR && (p.rowvec || p.rowvec2)) {
-            const int last = (m0 + PBM < p.M ? m0 + PBM : p.M) - 1;
+            const int last = (m0 + PBM < p.m_end ? m0 + PBM : p.m_end) - 1;
             e.img0 = m0 / p.rows_per_vec;
             e.nimg = last / p.rows_per_vec - e.img0 + 1;
         }
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         if (p.ln_stats != nullptr) {
             for (int r = tv; r < PBM; r += PNT) {
                 const int m = m0 + r;
-                lnrow[r] = ln_row_stats(p, m < p.M ? m : p.M - 1);
+                lnrow[r] = ln_row_stats(p, m < p.m_end ? m : p.m_end - 1);
             }
         }
     };
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
     int bid = blockIdx.x;
     int tm, tn;
     tile_of(bid, tm, tn);
-    int m0 = tm * PBM, n0 = tn * PBN;
+    int m0 = p.m_begin + tm * PBM, n0 = tn * PBN;
     setup(m0, n0);
     if (SPLIT) {
         const int kt0 = (int)((long long)kslice * nk_all / ksplit), kt1 = (int)((long long)(kslice + 1) * nk_all / ksplit);
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         int ntm = 0, ntn = 0;
         if (more) {
             tile_of(nbid, ntm, ntn);
-            setup(ntm * PBM, ntn * PBN);
+            setup(p.m_begin + ntm * PBM, ntn * PBN);
             kb = 0; tap = 0; c0b = 0;
 #pragma unroll
             for (int q = 0; q < PWP + PAP; ++q) dma_q(q, st ^ 1);
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         if (!more) break;
         __syncthreads();   // every wave is done with this tile's vectors / row statistics
         bid = nbid; tm = ntm; tn = ntn;
-        m0 = tm * PBM; n0 = tn * PBN;
+        m0 = p.m_begin + tm * PBM; n0 = tn * PBN;
         eplan = plan_of(m0);
         stage_tile_vectors(m0, n0, eplan);
         __syncthreads();   // + vmcnt(0): the next tile's first K-step has landed
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
 
 template <int AMODE, int EPI>
 int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
-    const int tilesN = d->N / PBN, tilesM = (d->M + PBM - 1) / PBM;
+    const int tilesN = d->N / PBN, tilesM = (d->m_end - d->m_begin + PBM - 1) / PBM;   // (the caller normalised the row range)
     const int ntiles = tilesM * tilesN;
     VkGemmDesc desc = *d;
     const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally

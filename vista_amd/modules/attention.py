@@ -92,6 +92,17 @@ class Packable:
     def invalidate_packed(self):
         self._pk = None
         object.__setattr__(self, "_pk_params", None)  # the parameter list is re-resolved on the next pack
+        _PACK_GEN[0] += 1   # anything that captured pointers into the old pack (a hipGraph of the forward) is stale from here on
+
+
+_PACK_GEN = [0]
+
+
+def pack_generation():
+    """Counts invalidate_packed() calls process-wide. A captured hipGraph of a forward holds raw pointers into packed weights; its cache
+    (sampling.FusedLoop._graph_for) compares this number, so an EMA swap through p.data + invalidate_packed(model), an in-place load into
+    inference tensors or any load_state_dict (post-hook) re-captures instead of replaying launches that read freed memory."""
+    return _PACK_GEN[0]
 
 
 def _invalidate_after_load(module, incompatible_keys):
@@ -248,7 +259,7 @@ class MemoryEfficientCrossAttention(nn.Module, Packable):
     def _pack(self, dev):
         if self.is_self:
             pk = {"out": ops.pack_linear(self.to_out[0].weight, self.to_out[0].bias, dev)}
-            if FP8["proj"]:
+            if FP8["proj"] and self.query_dim >= FP8_PROJ_MIN_WIDTH:   # (narrower blocks keep the bf16 out-projection: never read there)
                 pk["out8"] = ops.pack_linear_fp8(self.to_out[0].weight, self.to_out[0].bias, dev)
             return pk
         w, b = self.context_map()

@@ -66,13 +66,16 @@ class EulerEDMSampler(SingleStepDiffusionSampler):
     def __init__(self, s_churn=0.0, s_tmin=0.0, s_tmax=float("inf"), s_noise=1.0, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.s_churn, self.s_tmin, self.s_tmax, self.s_noise = s_churn, s_tmin, s_tmax, s_noise
+        # the churn noise source, `x -> standard normal tensor like x` (reference: torch.randn_like, sampling.py:81). A hook so that a caller
+        # -- like do_sample's noise_fn -- can inject its own draws (tests replay the draws recorded from the reference).
+        self.noise_fn = None
 
     # ---- generic path -------------------------------------------------------------------------------------------
     def sampler_step(self, sigma, next_sigma, denoiser, x, cond, cond_mask=None, uc=None, gamma=0.0):
         """sampling.py:78-89. sigma / next_sigma: (N,) device tensors."""
         sigma_hat = sigma * (gamma + 1.0)
-        if gamma > 0:  # stochastic churn (never enabled by Vista: s_churn = 0, sample_utils.py:212); torch RNG by design
-            eps = torch.randn_like(x) * self.s_noise
+        if gamma > 0:  # stochastic churn (never enabled by Vista: s_churn = 0, sample_utils.py:212); torch RNG unless noise_fn is set
+            eps = (torch.randn_like(x) if self.noise_fn is None else self.noise_fn(x).to(device=x.device, dtype=x.dtype)) * self.s_noise
             x = x + eps * append_dims(sigma_hat ** 2 - sigma ** 2, x.ndim) ** 0.5
         denoised = self.denoise(x, denoiser, sigma_hat, cond, cond_mask, uc)
         return ops.euler_step(x, denoised.float(), sigma_hat, next_sigma)  # x + (x - denoised)/sigma_hat * (next - sigma_hat)
@@ -195,11 +198,19 @@ class FusedLoop:
         device, allocated outside the capture -- and all warm-ups share one side stream."""
         unet = self.unet
         cache = unet.__dict__.setdefault("_hipgraph_cache", {})
+        from .. import attention as _att
+        # ... including the module-level switches that decide WHICH kernels forward_tokens launches (bench.py's config-5 side figure and the
+        # fp8 tests flip them in-process): a graph captured under other switches must not be replayed
+        switches = (tuple(sorted(_att.FP8.items())), _att.FF_FUSED, _att.QKV_SPLIT, _att.Q_LOG2, ops.TILE_CFG,
+                    None if self.unet_shard is None else getattr(self.unet_shard, "a2a_chunks", None))
         key = (tuple(net_in.shape), n_ts, tuple(self.ctx2.shape), tuple(self.y2.shape), tuple(self.mask2.shape), self.T, self.H, self.W,
-               None if self.unet_shard is None else id(self.unet_shard), str(net_in.device))
+               None if self.unet_shard is None else id(self.unet_shard), str(net_in.device), switches)
         g = cache.get(key)
-        from ..attention import Packable
-        wkey = tuple((id(q), Packable._param_version(q)) for q in unet.parameters())   # once per sampling run, not per step
+        # the captured launches hold raw pointers into the packed weights (owned by the modules' _pk, not by the graph pool): the key covers
+        # what Packable itself can see (identity + version counter of every parameter) AND the pack generation, which every
+        # invalidate_packed() bumps -- writes through p.data (EMA swap), in-place loads into inference tensors and the load_state_dict
+        # post-hooks are invisible to version counters but all go through invalidate_packed
+        wkey = (_att.pack_generation(),) + tuple((id(q), _att.Packable._param_version(q)) for q in unet.parameters())   # once per run, not per step
         if g is not None and g["wkey"] != wkey:
             g = None   # parameters were replaced / updated since the capture: its launches point at the old packed weights
         if g is None:

@@ -192,8 +192,15 @@ class _SplitKTLS(threading.local):
 _SPLITK_WS = _SplitKTLS()
 
 
-_GRAPH_WS = {}        # device -> the ONE workspace of every hipGraph warm-up / capture / replay on that device
-_GRAPH_WS_DEPTH = 0   # > 0 inside graph_workspace(): _splitk_workspace hands out _GRAPH_WS instead of a per-stream buffer
+_GRAPH_WS = {}        # (device, host thread) -> the ONE workspace of every hipGraph warm-up / capture / replay of that thread on that device
+
+
+class _GraphTLS(threading.local):
+    def __init__(self):
+        self.depth = 0   # > 0 inside graph_workspace() ON THIS THREAD: _splitk_workspace hands out _GRAPH_WS instead of a per-stream buffer
+
+
+_GRAPH_TLS = _GraphTLS()
 
 
 class graph_workspace:
@@ -203,18 +210,16 @@ class graph_workspace:
     other streams keeps its per-stream buffers."""
 
     def __enter__(self):
-        global _GRAPH_WS_DEPTH
-        dev = torch._C._cuda_getDevice()
-        if SPLITK_WS_BYTES and dev not in _GRAPH_WS:
+        key = (torch._C._cuda_getDevice(), threading.get_ident())   # thread ranks (tests) enqueue concurrently: one workspace each
+        if SPLITK_WS_BYTES and key not in _GRAPH_WS:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("ops.graph_workspace must be entered before the capture starts")
-            _GRAPH_WS[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{dev}")
-        _GRAPH_WS_DEPTH += 1
+            _GRAPH_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{key[0]}")
+        _GRAPH_TLS.depth += 1
         return self
 
     def __exit__(self, *exc):
-        global _GRAPH_WS_DEPTH
-        _GRAPH_WS_DEPTH -= 1
+        _GRAPH_TLS.depth -= 1
         return False
 
 
@@ -223,8 +228,8 @@ def _splitk_workspace(stream):
     different streams must not (include/vista_hip.h, VkGemmDesc.splitk_ws), and thread ranks (tests) share a stream but enqueue
     concurrently. Held in thread-local storage, so a worker thread's buffers are released when the thread exits. Inside
     graph_workspace() (hipGraph warm-up / capture) the device's single graph workspace is used instead."""
-    if _GRAPH_WS_DEPTH > 0:
-        return _GRAPH_WS[torch._C._cuda_getDevice()]
+    if _GRAPH_TLS.depth > 0:
+        return _GRAPH_WS[(torch._C._cuda_getDevice(), threading.get_ident())]
     key = (torch._C._cuda_getDevice(), stream.value)
     ws = _SPLITK_WS.ws.get(key)
     if ws is None:
@@ -242,9 +247,14 @@ class RowStats:
         self.t, self.parts, self.M = t, parts, M
 
 
+ROW_RANGE = None  # tests: (m_begin, m_end) -> the next GEMM calls compute only those output rows (VkGemmDesc.m_begin / m_end, ABI v5)
+
+
 def _gemm(desc, emit_stats=False, device=None):
     lib = _lib.load()
     desc.tile_cfg = TILE_CFG
+    if ROW_RANGE is not None:
+        desc.m_begin, desc.m_end = ROW_RANGE
     stream = _stream()
     if SPLITK_WS_BYTES:
         ws = _splitk_workspace(stream)
