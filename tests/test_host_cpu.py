@@ -498,8 +498,8 @@ def test_gemm_launch_rules_are_pinned():
 
 
 def test_gemm_tail_split_rule_is_pinned():
-    """vk_gemm_tail_split: where vk_gemm_bf16 cuts a one-tile-per-workgroup launch into whole rounds + a 128x160 tail (round 5). Host arithmetic only.
-    Level 0 of the BASELINE window is 460800 rows = 1800 row tiles of 256: 7.03 rounds at N = 320 (tail = the last 8 row tiles), 21.09 at N = 960."""
+    """vk_gemm_tail_split: where vk_gemm_bf16 cuts a one-tile-per-workgroup launch into whole rounds + a 128x160 tail (round 5; measured without
+    gain and therefore OFF unless VISTA_GEMM_TAIL=<percent> or tile_cfg bit 6 asks for it -- which this test does). Host arithmetic only. Level 0 of the BASELINE window is 460800 rows = 1800 row tiles of 256: 7.03 rounds at N = 320 (tail = the last 8 row tiles), 21.09 at N = 960."""
     import ctypes as C
     from vista_amd import _lib, ops
     lib = _lib.load()
@@ -511,6 +511,7 @@ def test_gemm_tail_split_rule_is_pinned():
         d.M, d.N, d.K, d.lda, d.ldc = M, N, K, K, N
         d.amode, d.epi, d.alpha = amode, ops.EPI_LINEAR, 1.0
         d.splitk_ws, d.splitk_ws_bytes = one, 160 << 20
+        d.tile_cfg = 64   # ask for the rule
         if stats:
             d.rowstat_out = one
         if amode == ops.AMODE_CONV3X3:
@@ -532,3 +533,4 @@ def test_gemm_tail_split_rule_is_pinned():
     assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, tile_cfg=7) == 0      # a forced variant is never split
     assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, m_begin=256, m_end=full) == 256 + 1792 * 256   # 1799 tiles of a row range: 7 rounds + 7
     assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, m_begin=5, m_end=4) < 0      # bad range
+    assert split(full, 960, 320, tile_cfg=0) == 0                                                      # not asked for: off by default

@@ -664,10 +664,7 @@ def test_gemm_tail_split_and_row_ranges_are_bitwise(kind, n, H, W):
     Every output element sees the same MFMA sequence and the row-sum slabs are the same 160-column blocks, so (a) the launcher's own (split)
     launch, (b) the forced single launch (tile_cfg 7 disables the split) and (c) three explicit row-range calls that together cover the rows
     must agree BIT FOR BIT -- outputs and row sums -- and match torch fp32. Reference call sites as test_gemm_pipe_is_bitwise_..."""
-    import ctypes as C
-    from vista_amd import _lib
     ops = _ops()
-    lib = _lib.load()
     Cc, S = 320, H * W
     M = n * S
     x = rnd(M, Cc)
@@ -703,7 +700,11 @@ def test_gemm_tail_split_and_row_ranges_are_bitwise(kind, n, H, W):
         fn = lambda **kw: ops.conv_t3(x3, pw, n, S, res2=x3, alpha=0.3, beta=1.0, **kw)  # noqa: E731
         N = Cc
     stats = kind == "dense_K4N+res+stats"
-    auto = fn(emit_stats=True) if stats else fn()
+    ops.TILE_CFG = 64   # the launcher's own choice + the tail-split rule (an A/B option, measured without gain and off by default)
+    try:
+        auto = fn(emit_stats=True) if stats else fn()
+    finally:
+        ops.TILE_CFG = 0
     ops.TILE_CFG = 7
     try:
         single = fn(emit_stats=True) if stats else fn()
@@ -715,10 +716,9 @@ def test_gemm_tail_split_and_row_ranges_are_bitwise(kind, n, H, W):
         _check_stats(sa, auto)
     close(auto.reshape(M, N), ref, f"tail split {kind}")
     assert torch.equal(auto, single), "split and single launches must agree bit for bit"
-    # the launcher did split (host query), at a whole number of full rounds
+    # the shape is one the rule splits: at least one full round and a last round filled to <= 40 %
     tiles_n, tiles_m = N // 320, (M + 255) // 256
-    full = tiles_m * tiles_n // 256
-    assert full >= 1 and 0 < tiles_m * tiles_n % 256 <= 0.4 * 256
+    assert tiles_m * tiles_n // 256 >= 1 and 0 < tiles_m * tiles_n % 256 <= 0.4 * 256
     # (c) explicit row ranges: [0, a) on whatever the launcher picks, [a, b) and [b, M) likewise, written into one output
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
     a, b_ = 256 * 100 + 64, M - 300   # deliberately not tile aligned

@@ -111,14 +111,14 @@ __device__ __forceinline__ float dot2_ones(uint32_t packed, float acc) {  // acc
 // is bound by its VALU, not by the matrix core: 64 quarter-rate exponentials = 1024 cycles already equal the tile's 32 MFMAs). Any base is
 // exact in exact arithmetic; base 0 is safe in fp32 / bf16 because the first tile's maximum >= -60 bounds the row sum away from zero and an
 // exponent above 127 overflows to +inf, fails the row-sum test and re-bases the row on its true maximum (general path from then on).
+// The whole kernel as a device function over the workgroup's LDS (2 x 16 KiB) and its logical block index, so that the pipelined kernel below
+// (attn_spatial_pipe_kernel) can fall back to it for a workgroup whose rows leave the zero-base range.
 template <int NW, int QW, bool VROW, bool PRE>
-__global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
-                                                                                const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
-                                                                                int n_img, int heads, int S, int ldq, int ldk, int ldo,
-                                                                                float scale_log2, float rescale_thr, int ldv) {
+__device__ __forceinline__ void attn_spatial_body(char* const smem, const int logical, const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                  const uint16_t* __restrict__ vt, uint16_t* __restrict__ o, int n_img, int heads, int S, int ldq,
+                                                  int ldk, int ldo, float scale_log2, float rescale_thr, int ldv) {
     constexpr int QB = NW * QW * 32;  // query rows per workgroup
     constexpr int GPW = 8 / NW;       // 8-row DMA groups of each tile handled per wave
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // per stage: K tile 8 KiB | V^T tile 8 KiB
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -126,7 +126,6 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     const int nqb = (S + QB - 1) / QB;
-    const int logical = xcd_remap(blockIdx.x, nqb * n_img * heads);
     const int bh = logical / nqb, qb = logical - bh * nqb;
     const int img = bh / heads, head = bh - img * heads;
 
@@ -403,6 +402,253 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(
                     *(uint2*)(optr + 32 * d + 8 * g) = w;
                 }
         }
+    }
+}
+
+template <int NW, int QW, bool VROW, bool PRE>
+__global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                                                const uint16_t* __restrict__ vt, uint16_t* __restrict__ o,
+                                                                                int n_img, int heads, int S, int ldq, int ldk, int ldo,
+                                                                                float scale_log2, float rescale_thr, int ldv) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];  // per stage: K tile 8 KiB | V^T tile 8 KiB
+    const int nqb = (S + NW * QW * 32 - 1) / (NW * QW * 32);
+    attn_spatial_body<NW, QW, VROW, PRE>(smem, xcd_remap(blockIdx.x, nqb * n_img * heads), q, k, vt, o, n_img, heads, S, ldq, ldk, ldo, scale_log2,
+                                         rescale_thr, ldv);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: software-pipelined form of the zero-base kernel (PRE, VROW) for long sequences, S a multiple of the workgroup's NW x 64 query rows.
+// The un-pipelined loop above costs the SUM of its matrix and its VALU issue time (scores -> barrier-free but serial: 16 MFMAs, then ~160 VALU,
+// then 16 MFMAs per wave and tile). Here the work is cut into UNITS of (32 keys x 32 queries) -- 4 score MFMAs chained on one accumulator,
+// 16 v_exp + 8 v_cvt_pk + 16 v_add, 4 PV MFMAs -- and unit n's VALU work is issued in the gaps between the score MFMAs of unit n + 1 and the
+// PV MFMAs of unit n - 1: one MFMA, then 2 exp + 1 cvt + 2 add (the five single-issue fillers that fit one 32-cycle MFMA of a wave that owns
+// its SIMD, MI355X_MICROARCH.md "Per-instruction cycle constants"), then the next MFMA on ANOTHER accumulator (score k-steps alternate with
+// the two PV accumulators: an MFMA never waits on its predecessor). tools/probes/attn_issue_probe.hip measures exactly this stream.
+//   * four units per 64-key tile: (key block c, query block b) = (0,0) (0,1) (1,0) (1,1); two score accumulators and two packed-P buffers
+//     alternate with the unit parity. The K fragments of a key block serve two consecutive units (b = 1 of one key block pair ... b = 0 of the
+//     next) and so do the V^T fragments one unit later: each fragment register is RELOADED with the next key block's fragment right after the
+//     MFMA that used it last (ds_read_b128 after the even MFMAs, two ds_read_b64_tr_b16 after the odd ones, in the b = 0 units), eight gaps
+//     before its next use -- single-buffered fragments, 32 registers instead of 64, at most two LDS reads per gap;
+//   * no row maxima and no per-tile validation at all: every row runs on base 0 (a score is the base-2 exponent, the query carries
+//     scale x log2 e) and the kernel checks ONCE, at the end, that each row's sum is finite and within 2^+-100; a workgroup that fails the
+//     test (scores beyond +-100 octaves: never on real activations) recomputes its rows with attn_spatial_body, the general online softmax;
+//   * row sums are plain f32 adds of the un-rounded probabilities (v_dot2c on the packed pair costs ~10 cycles beside MFMAs, same guide table);
+//   * LDS rings, ONE barrier per tile (B_t, after the first MFMA of tile t's third unit): K(t)'s last fragment read is in the first unit of
+//     tile t and K(t + 1)'s first one right after B_t -> K ring of two 8 KiB stages, the DMA of K(t + 2) goes out at B_t; V(t) is read in the
+//     first and third unit of tile t, i.e. still after B_t -> V ring of THREE stages, the DMA of V(t + 2) goes out at B_t into V(t - 1)'s;
+//     every DMA has a whole tile to land and is retired by the vmcnt(0) of the next barrier. 40 KiB of LDS;
+//   * 256-register budget (launch bound 2 waves per SIMD): the score accumulators must be arch VGPRs for v_exp to read them -- with the
+//     512-register budget of a one-wave-per-SIMD declaration the compiler parks MFMA results in AGPRs and pays a v_accvgpr_read per score.
+//     NW = 4: four waves, one per SIMD when one workgroup runs per CU, or two unsynchronised workgroups per CU; NW = 8: two waves per SIMD.
+template <int NW, bool ONE_PER_CU>
+__global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+                                                                        const uint16_t* __restrict__ v, uint16_t* __restrict__ o, int n_img,
+                                                                        int heads, int S, int ldq, int ldk, int ldo, int ldv) {
+    constexpr int QB = NW * 64;   // query rows per workgroup: two 32-row blocks per wave
+    constexpr int GPW = 8 / NW;   // 8-row DMA groups of each tile handled per wave
+    // K ring: 2 x 8 KiB at 0; V ring ([key][64 d] rows): 3 x 8 KiB at 16 KiB. ONE_PER_CU: the declaration is padded past half of the CU's
+    // 160 KiB so that a four-wave workgroup has its SIMDs to itself (the padding is never touched)
+    constexpr int V_RING = 16384;
+    __shared__ __attribute__((aligned(16))) char smem[40960 + (ONE_PER_CU ? 48 * 1024 : 0)];
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    typedef short s4_t __attribute__((ext_vector_type(4)));
+    typedef s4_t __attribute__((address_space(3))) * lds_s4_t;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int nqb = S / QB;
+    const int logical = xcd_remap(blockIdx.x, nqb * n_img * heads);
+    const int bh = logical / nqb, qb = logical - bh * nqb;
+    const int img = bh / heads, head = bh - img * heads;
+
+    // ---- Q fragments (B operand of the score MFMA: column = query row, 8 consecutive d at 16 ks + 8 lh) ----
+    bf16x8_t qf[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int qrow = qb * QB + (wave * 2 + b) * 32 + l31;
+        const uint16_t* qptr = q + ((size_t)img * S + qrow) * ldq + head * 64 + 8 * lh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[b][ks] = *(const bf16x8_t*)(qptr + 16 * ks);
+    }
+
+    // ---- K / V staging by LDS-DMA, images exactly as attn_spatial_body<.., VROW = true> lays them out: two per-lane source offsets live
+    //      across the loop, everything else of a piece's address is uniform ----
+    const char* const kbase = (const char*)(k + (size_t)img * S * ldk + head * 64);
+    const char* const vbase = (const char*)(v + (size_t)img * S * ldv + head * 64);
+    uint32_t k_off0, v_off0;   // group 0's per-lane source offsets; group i (NW = 4: i = 0, 1) is 32 keys further: a uniform + 32 rows
+    {
+        const int rho = 8 * wave + (lane >> 3), dslot = lane & 7;                   // LDS row of both tiles handled by this lane (group 0)
+        const int key = (rho & 32) + key_of_row(rho & 31);                          // key stored in K row rho (permuted: see key_of_row)
+        k_off0 = (uint32_t)(key * ldk + (dslot ^ ((rho >> 1) & 7)) * 8) * 2u;        // swizzle on the SOURCE chunk
+        v_off0 = (uint32_t)(rho * ldv + (dslot ^ (((rho >> 1) & 1) << 2)) * 8) * 2u; // V row rho = key rho: 64-byte halves swapped by key bit 1
+    }
+    auto dma_tile = [&](const int t, const int kst, const int vst) __attribute__((always_inline)) {
+        char* sK = smem + kst * 8192 + wave_u * 1024;
+        char* sV = smem + V_RING + vst * 8192 + wave_u * 1024;
+        const char* kt = kbase + (size_t)t * 64 * ldk * 2;   // uniform
+        const char* vt = vbase + (size_t)t * 64 * ldv * 2;
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {   // (NW * i = 4 i: rows rho + 32 i -> keys + 32 i under both images' layouts)
+            __builtin_amdgcn_global_load_lds((gptr_t)(kt + (size_t)(32 * i) * ldk * 2 + k_off0), (lptr_t)(sK + i * NW * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vt + (size_t)(32 * i) * ldv * 2 + v_off0), (lptr_t)(sV + i * NW * 1024), 16, 0, 0);
+        }
+    };
+
+    // fragment read offsets (as attn_spatial_body): K row l31 (+ 32 per key block), logical chunk (2 ks + lh) ^ fsw under the row swizzle = the
+    // ks = 0 offset with bits 5-6 XORed by ks: ONE address register + a v_xor per read instead of four (registers are what this loop is short
+    // of); V through the transposing read, whose two d-half bases differ by the 64-byte half swap = XOR 64 likewise
+    const int fsw = (l31 >> 1) & 7;
+    const int kfrag0 = l31 * 128 + ((lh ^ fsw) << 4);
+    int vtr0;
+    {
+        const int kq = (l31 & 15) >> 2, g1 = (l31 >> 4) & 1, c = l31 & 3, sw1 = (kq >> 1) & 1;
+        vtr0 = (8 * lh + kq) * 128 + (2 * g1 + (c >> 1)) * 16 + (c & 1) * 8 + sw1 * 64;
+    }
+
+    // ---- pipeline state ----
+    f32x16_t oacc[2][2];          // [query block b][d half]
+    f32x16_t sc[2];               // score accumulators: unit parity
+    uint32_t pw[2][8];            // packed probabilities of a unit (two k-slot fragments): unit parity
+    bf16x8_t kf[4];               // K fragments of the key block the coming score MFMAs use, [k-step]
+    bf16x8_t vf[4];               // V^T fragments of the key block the coming PV MFMAs use, [2 * d half + k-slot within the block]
+    float ps[2][2];               // row-sum partials [query block][chain]
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        ps[b][0] = 0.f; ps[b][1] = 0.f;
+        oacc[b][0] = zero16; oacc[b][1] = zero16;
+    }
+    auto read_k = [&](const char* sK, const int c, const int ks) __attribute__((always_inline)) {
+        kf[ks] = *(const bf16x8_t*)(sK + c * 32 * 128 + (kfrag0 ^ (ks << 5)));
+    };
+    // V fragment f = 2 * d + j of key block c: row d half d, keys 32 c + 16 j + 8 lh ... -- two transposing 8-byte reads
+    auto read_v = [&](const char* sV, const int c, const int f) __attribute__((always_inline)) {
+        const int d = f >> 1, J = 2 * c + (f & 1);
+        const int vb = vtr0 ^ (d << 6);
+        const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sV + vb + J * 2048));
+        const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(sV + vb + J * 2048 + 512));
+        bf16x8_t r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        vf[f] = r;
+    };
+    auto p_frag = [&](const uint32_t* w4) __attribute__((always_inline)) -> bf16x8_t {
+        const uint4 u = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        return __builtin_bit_cast(bf16x8_t, u);
+    };
+
+    const int nt = S >> 6;
+    // ---- prologue: tiles 0 and 1 in flight, K(0, block 0) fragments, the first unit's scores. The loop body is uniform: the first unit's
+    //      "previous unit" is a zero probability block (pw[1] = 0 against finite V fragments adds nothing), and the last tile's reads of a
+    //      tile t + 1 hit a stale (finite or not: never consumed) stage ----
+    dma_tile(0, 0, 0);
+    if (nt > 1) dma_tile(1, 1, 1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pw[1][i] = 0u;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) vf[f] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) read_k(smem, 0, ks);
+    sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][0], zero16, 0, 0, 0);
+#pragma unroll
+    for (int ks = 1; ks < 4; ++ks) sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[0][ks], sc[0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // One unit slot. SL = 0..3 = (key block c = SL >> 1, query block b = SL & 1) of tile t; kst / vst = ring stages of tile t (K: t & 1, V: t % 3).
+    //   VALU : softmax of sc[SL & 1] -> pw[SL & 1], ps[b]
+    //   MFMA : even gaps -- scores of the NEXT unit into sc[(SL & 1) ^ 1] from kf; odd gaps -- PV of the PREVIOUS unit from pw[(SL & 1) ^ 1] and vf
+    //   LDS  : b = 0 units reload each fragment right after its last use: SL 0: kf <- K(t, block 1), vf <- V(t, block 0);
+    //                                                                  SL 2: kf <- K(t + 1, block 0), vf <- V(t, block 1)
+    //   SL 2 : the tile's barrier B_t after the first MFMA (K(t + 1), V(t + 1) landed; K(t), V(t - 1) dead), then the DMA of tile t + 2
+    auto slot = [&](auto sl_tag, const int t, const int kst, const int vst) __attribute__((always_inline)) {
+        constexpr int SL = decltype(sl_tag)::value;
+        constexpr int b = SL & 1, par = SL & 1;
+        constexpr int nb = b ^ 1, pb = b ^ 1;                   // query block of the next / previous unit
+        const char* const sK_cur = smem + kst * 8192;
+        const char* const sK_nxt = smem + (kst ^ 1) * 8192;
+        const char* const sV_cur = smem + V_RING + vst * 8192;
+        f32x16_t& cur = sc[par];
+        f32x16_t& nxt = sc[par ^ 1];
+        uint32_t* const pcur = pw[par];
+        const uint32_t* const pprev = pw[par ^ 1];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if ((g & 1) == 0) {
+                const int ks = g >> 1;
+                nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[nb][ks], ks == 0 ? zero16 : nxt, 0, 0, 0);
+                if (SL == 2 && g == 0) {
+                    __syncthreads();   // B_t. vmcnt(0): this wave's pieces of tile t + 1 have landed; lgkmcnt(0): no fragment read is pending
+                    if (t + 2 < nt) dma_tile(t + 2, kst, vst == 0 ? 2 : vst - 1);   // K(t + 2) over K(t); V(t + 2) over V(t - 1): stage (t + 2) % 3 = (t - 1) % 3
+                }
+                if (SL == 0) read_k(sK_cur, 1, ks);
+                if (SL == 2) read_k(sK_nxt, 0, ks);
+            } else {
+                const int d = (g >> 1) & 1, j = g >> 2, f = 2 * d + j;
+                oacc[pb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[f], p_frag(pprev + 4 * j), oacc[pb][d], 0, 0, 0);
+                if (SL == 0) read_v(sV_cur, 0, f);
+                if (SL == 2) read_v(sV_cur, 1, f);
+            }
+            {   // the five fillers of this gap
+                const float e0 = fast_exp2(cur[2 * g]), e1 = fast_exp2(cur[2 * g + 1]);
+                uint32_t w = pack_bf16(e0, e1);
+                asm volatile("" : "+v"(w));   // pinned HERE: the optimiser otherwise sinks the conversions to their use, a whole unit later
+                pcur[g] = w;
+                // single v_add_f32 each, as asm: left to the optimiser the sixteen adds of a unit are SLP-packed into v_pk_add_f32 (slower beside
+                // MFMAs, same guide table) and gathered at the end of the unit, which keeps all sixteen exponentials live until then
+                asm("v_add_f32 %0, %1, %2" : "=v"(ps[b][0]) : "v"(ps[b][0]), "v"(e0));
+                asm("v_add_f32 %0, %1, %2" : "=v"(ps[b][1]) : "v"(ps[b][1]), "v"(e1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        int vst = 0;
+#pragma unroll 1
+        for (int t = 0; t < nt; ++t) {
+            slot(std::integral_constant<int, 0>{}, t, t & 1, vst);
+            slot(std::integral_constant<int, 1>{}, t, t & 1, vst);
+            slot(std::integral_constant<int, 2>{}, t, t & 1, vst);
+            slot(std::integral_constant<int, 3>{}, t, t & 1, vst);
+            vst = vst == 2 ? 0 : vst + 1;
+        }
+    }
+    // PV of the very last unit (key block 1, query block 1)
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * d + j], p_frag(pw[1] + 4 * j), oacc[1][d], 0, 0, 0);
+
+    // ---- the one validity test of the zero-base run: finite row sums inside 2^+-100 ----
+    float inv[2];
+    bool bad = false;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const float l = ps[b][0] + ps[b][1];
+        const float l_tot = l + __shfl_xor(l, 32, 64);
+        bad = bad || !(l_tot >= 0x1p-100f && l_tot <= 0x1p100f);
+        inv[b] = 1.f / l_tot;
+    }
+    if (__syncthreads_or(bad)) {   // (also a barrier: every wave is done with the LDS ring) -- workgroup-uniform, never taken on real activations
+        attn_spatial_body<NW, 2, true, true>(smem, logical, q, k, v, o, n_img, heads, S, ldq, ldk, ldo, 1.0f, RESCALE_THR, ldv);
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int qrow = qb * QB + (wave * 2 + b) * 32 + l31;
+        uint16_t* optr = o + ((size_t)img * S + qrow) * ldo + head * 64 + 4 * lh;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack_bf16(oacc[b][d][4 * g + 0] * inv[b], oacc[b][d][4 * g + 1] * inv[b]);
+                w.y = pack_bf16(oacc[b][d][4 * g + 2] * inv[b], oacc[b][d][4 * g + 3] * inv[b]);
+                *(uint2*)(optr + 32 * d + 8 * g) = w;
+            }
     }
 }
 
@@ -1031,6 +1277,26 @@ static int attn_spatial_launch(const void* q, const void* k, const void* vt, voi
                        (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, scale * LOG2E, thr, ldv)
     if (pre && ldv <= 0) return VK_EINVAL;  // the pre-scaled form exists for the q | k | v column-block layout only
     if (pre) scale = 1.f / LOG2E;           // a score is already the base-2 exponent: scale_log2 = 1 for the general kernels below
+    // Round 5: the software-pipelined zero-base kernel for long sequences made of whole workgroups of query rows (level 0: S = 9216).
+    // VISTA_ATTN_PIPE: 0 = off (A/B hook), 1 = four waves x 64 rows, two workgroups per CU, 2 = four waves, one workgroup per CU (one wave per
+    // SIMD), 3 = eight waves (two per SIMD in one workgroup).
+    static const int pipe_mode = [] { const char* e = getenv("VISTA_ATTN_PIPE"); return e ? atoi(e) : 1; }();
+    if (pre && pipe_mode > 0 && S >= 2048 && (ldo % 4) == 0) {
+        const int rows = pipe_mode == 3 ? 512 : 256;
+        if (S % rows == 0) {
+            const long long nb = (long long)(S / rows) * n_img * heads;
+            if (nb > 0x7fffffffLL) return VK_EINVAL;
+#define ATTN_PIPE_LAUNCH(NW, ONE)                                                                                                             \
+    hipLaunchKernelGGL((attn_spatial_pipe_kernel<NW, ONE>), dim3((unsigned)nb), dim3(NW * 64), 0, (hipStream_t)stream_, (const uint16_t*)q,    \
+                       (const uint16_t*)k, (const uint16_t*)vt, (uint16_t*)o, n_img, heads, S, ldq, ldk, ldo, ldv)
+            if (pipe_mode == 3) ATTN_PIPE_LAUNCH(8, false);
+            else if (pipe_mode == 2) ATTN_PIPE_LAUNCH(4, true);
+            else ATTN_PIPE_LAUNCH(4, false);
+#undef ATTN_PIPE_LAUNCH
+            VK_CHECK_LAUNCH();
+            return VK_OK;
+        }
+    }
     if (pre && cls == 2) {
         // zero-base kernel for the 512-row form only (241 VGPRs of its 256): 5.12 -> 4.95 ms per level-0 launch (1.06 -> 1.10 PFLOP/s). The
         // 256- / 128-row forms live at 128 VGPRs for four waves per SIMD; the second probability path spills there (0.69 -> 0.81 ms at

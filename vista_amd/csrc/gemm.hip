@@ -538,9 +538,14 @@ inline void tile_geometry(int cfg, int& bn, int& wn) {
 // be filled to at most VISTA_GEMM_TAIL percent, the whole rounds run as rows [m_begin, m_split) on the pipelined kernel and the remaining
 // rows [m_split, m_end) as a second launch of 128x160 tiles (four waves, two workgroups per CU: a quarter of the work per workgroup, all of
 // them resident at once) -- the same MFMA sequence per output element, the same row-sum slabs (160 columns each): bitwise the same result
-// as the single launch (tests/test_kernels_gpu.py::test_gemm_tail_split_is_bitwise). Returns the split row, 0 = no split.
+// as the single launch (tests/test_kernels_gpu.py::test_gemm_tail_split_and_row_ranges_are_bitwise). Returns the split row, 0 = no split.
+// MEASURED (round 5, profiles/r05_tail_split_experiment.txt) and NOT adopted: the split changes nothing (level-0 conv3x3 0.7239 vs 0.7245 ms,
+// q|k|v 0.4602 vs 0.4626, temporal conv 0.318 vs 0.306; step 169.4 vs 169.5 ms). The eight tiles of the "eighth round" do not cost a round: alone
+// on the chip they run ~2.4x faster than a tile among 255 others (no HBM / L2 contention, and the clock is no longer held down by the power
+// of 256 busy CUs), which is about what the extra launch costs. The rule stays available as VISTA_GEMM_TAIL=<percent> (A/B hook), default off.
 inline int tail_split_row(const VkGemmDesc* d, const TileChoice& t) {
-    static const int max_pct = [] { const char* e = getenv("VISTA_GEMM_TAIL"); return e ? atoi(e) : 40; }();
+    static const int env_pct = [] { const char* e = getenv("VISTA_GEMM_TAIL"); return e ? atoi(e) : 0; }();   // OFF by default: see the note above
+    const int max_pct = (d->tile_cfg & 64) ? 40 : env_pct;   // tile_cfg bit 6: the caller asks for the split rule (tests)
     if (max_pct <= 0 || t.cfg != 7 || t.ksplit != 1 || (d->tile_cfg & 7) != 0 || d->epi != EPI_LINEAR || d->out_f32 || (d->N % 320) != 0) return 0;
     const int rows = d->m_end - d->m_begin;
     const long long tilesN = d->N / 320, tilesM = (rows + 255) / 256, ntiles = tilesM * tilesN;
@@ -593,7 +598,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 
 inline int validate(const VkGemmDesc* d) {
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || d->tile_cfg > 7) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & ~64) > 7) return VK_EINVAL;
     if (d->m_begin < 0 || d->m_end < 0 || d->m_end > d->M || (d->m_end != 0 && d->m_begin >= d->m_end) || (d->m_end == 0 && d->m_begin >= d->M)) return VK_EINVAL;
     if ((d->m_begin != 0 || (d->m_end != 0 && d->m_end != d->M)) && d->epi == EPI_TRANS) return VK_EINVAL;   // (row ranges: LINEAR / GEGLU)
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
