@@ -11,7 +11,9 @@ LIBDIR = os.path.join(ROOT, "lib")
 LIB = os.path.join(LIBDIR, "libvista_hip.so")
 # per-file flags. ff_fused.hip: the SLP vectorizer packs the GEGLU arithmetic into v_pk_fma_f32 / v_pk_mul_f32 and pays for the operand
 # pairing with a v_mov per packed instruction -- a third more VALU instructions in a kernel whose in-projection waves are VALU-issue bound
-EXTRA_FLAGS = {"ff_fused.hip": ["-fno-slp-vectorize"]}
+# attention.hip: the pipelined spatial kernel's row-sum adds must stay single v_add_f32 (packed they are gathered at the end of a unit and keep
+# its sixteen exponentials live: spills in a loop that is 256 registers wide)
+EXTRA_FLAGS = {"ff_fused.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"]}
 SOURCES = ["gemm.hip", "gemm_pipe.hip", "gemm_stream.hip", "gemm_fp8.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 
 

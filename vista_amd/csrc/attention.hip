@@ -575,6 +575,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
         f32x16_t& nxt = sc[par ^ 1];
         uint32_t* const pcur = pw[par];
         const uint32_t* const pprev = pw[par ^ 1];
+        float ea = 0.f, eb = 0.f;   // the exponentials of score pair g, taken ONE gap ahead of their conversion and row-sum adds
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             if ((g & 1) == 0) {
@@ -592,15 +593,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
                 if (SL == 0) read_v(sV_cur, 0, f);
                 if (SL == 2) read_v(sV_cur, 1, f);
             }
-            {   // the five fillers of this gap
-                const float e0 = fast_exp2(cur[2 * g]), e1 = fast_exp2(cur[2 * g + 1]);
-                uint32_t w = pack_bf16(e0, e1);
+            {   // the fillers of this gap: exponentials of pair g + 1 (gap 0: of pair 0 too), conversion and row-sum adds of pair g. A
+                // transcendental's result may not be read by the next instruction; one gap of distance keeps every use clear of that
+                // hazard without the s_nop the compiler otherwise puts between each v_exp pair and its v_cvt_pk (20 per tile).
+                if (g == 0) { ea = fast_exp2(cur[0]); eb = fast_exp2(cur[1]); }
+                float na = 0.f, nb2 = 0.f;
+                if (g < 7) { na = fast_exp2(cur[2 * g + 2]); nb2 = fast_exp2(cur[2 * g + 3]); }
+                uint32_t w = pack_bf16(ea, eb);
                 asm volatile("" : "+v"(w));   // pinned HERE: the optimiser otherwise sinks the conversions to their use, a whole unit later
                 pcur[g] = w;
-                // single v_add_f32 each, as asm: left to the optimiser the sixteen adds of a unit are SLP-packed into v_pk_add_f32 (slower beside
-                // MFMAs, same guide table) and gathered at the end of the unit, which keeps all sixteen exponentials live until then
-                asm("v_add_f32 %0, %1, %2" : "=v"(ps[b][0]) : "v"(ps[b][0]), "v"(e0));
-                asm("v_add_f32 %0, %1, %2" : "=v"(ps[b][1]) : "v"(ps[b][1]), "v"(e1));
+                ps[b][0] += ea;   // (single v_add_f32: the file is built with -fno-slp-vectorize -- packed into v_pk_add_f32 the sixteen adds of
+                ps[b][1] += eb;   //  a unit are gathered at its end, keep sixteen exponentials live, and cost more beside MFMAs, same guide table)
+                asm volatile("" : "+v"(ps[b][0]), "+v"(ps[b][1]));   // pinned like the conversions: left alone the adds sink into the next basic block in a clump
+                ea = na; eb = nb2;
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -414,18 +414,9 @@ __device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev
 // branch), because the sixteen-wave kernels live at the 128-VGPR cap with 64-80 accumulator registers: a residual that had to be spilled
 // would be WAITED for at the spill, which is exactly the serialisation this epilogue removes. Absent row vectors are staged as zeros and
 // added unconditionally (x + 0 is exact); the LayerNorm fold is a template flag (two more ds_reads and eight fmas per quad).
-// Round 5, `stage_rows` (optional, wave-uniform): a wave-private LDS region of 32 x EPI_ROW_STRIDE(NW) bytes. When given, the packed bf16
-// row block of a wave tile (32 rows x NW columns: each lane holds 32-byte pieces of ONE row, so a store instruction would touch 32 rows x
-// 32 bytes) is first written there row-major and then read back chunk-linear -- lane l takes the 16-byte chunk 64 i + l of the block -- so
-// that every global store instruction writes 1 KiB of CONSECUTIVE row bytes (3.2 whole 320-byte row segments for the 160-column wave
-// tiles): the epilogue of these GEMMs is store-ISSUE bound and a scattered store costs the memory pipeline one pass per line touched.
-// Rows are padded to EPI_ROW_STRIDE so that the eight lanes of a ds_write_b128 group (eight consecutive rows) hit disjoint banks.
-// Arithmetic, row sums and residual loads are unchanged: results are bitwise the same.
-__host__ __device__ constexpr int epi_row_stride(int nw) { return nw * 2 + 16; }
-
 template <int NRES, bool LN, bool MX, int FX, int FY, int FM, int FN, int BN, int CAP>
 __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
-                                                         int stat_part, const float2* lnrow, const float* ev, int img0, char* stage_rows = nullptr) {
+                                                         int stat_part, const float2* lnrow, const float* ev, int img0) {
     constexpr int MW = FM * 32, NW = FN * 32, U = FX * FY;
     // ring depth: what fits beside the accumulators (16 registers per unit), ~36 registers of addresses / per-quad temporaries and the
     // 128-VGPR cap, at 8 registers per unit and residual tensor
@@ -530,11 +521,7 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
                 }
             } else {
                 const uint4 s0 = widen_pair(packed[0], packed[1]), s1 = widen_pair(packed[2], packed[3]);
-                if (stage_rows != nullptr) {   // (kernel-uniform) row l31 of the staged block, byte fi * 64 + 16 lh (+ 32): where the global store would have gone in its row
-                    char* const sr = stage_rows + l31 * epi_row_stride(NW) + fi * 64 + 16 * lh;
-                    *(uint4*)sr = s0;
-                    *(uint4*)(sr + 32) = s1;
-                } else if (row_ok[fj]) {
+                if (row_ok[fj]) {
                     *(uint4*)(outb + oo[fj] + fi * 64) = s0;
                     *(uint4*)(outb + oo[fj] + fi * 64 + 32) = s1;
                 }
@@ -546,33 +533,12 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
             const float so = __shfl_xor(ssum, 32, 64), qo = __shfl_xor(qsum, 32, 64);
             if (lh == 0 && row_ok[fj]) ((float2*)p.rowstat_out)[(size_t)stat_part * p.M + mrow[fj]] = make_float2(ssum + so, qsum + qo);
         }
-        if constexpr (!mx_tile) {
-            if (stage_rows != nullptr) {
-                // the staged 32 x NW block leaves chunk-linear: lane l stores chunks l, l + 64, ... (16 bytes each, CH per row)
-                constexpr int CH = NW * 2 / 16, PER = (32 * CH + 63) / 64;
-                static_assert(NW % 8 == 0, "whole 16-byte chunks per row");
-                const int lane = l31 + 32 * lh;
-                int r = lane / CH, c = lane - r * CH;
-                const int mblk = m0 + wm * MW + fj * 32;
-                const uint32_t colb = (uint32_t)(n0 + wn * NW - (p.mx8_out ? p.mx8_cols : 0)) * 2u;
-#pragma unroll
-                for (int i = 0; i < PER; ++i) {
-                    if (32 * CH % 64 == 0 || r < 32) {
-                        const uint4 v = *(const uint4*)(stage_rows + r * epi_row_stride(NW) + c * 16);
-                        if (r < 32 && mblk + r < p.m_end) *(uint4*)(outb + ((uint32_t)(mblk + r) * (uint32_t)p.ldc) * 2u + colb + c * 16) = v;
-                    }
-                    c += 64 % CH;
-                    r += 64 / CH;
-                    if (c >= CH) { c -= CH; r += 1; }
-                }
-            }
-        }
     }
 }
 
 template <int FX, int FY, int FM, int FN, int BN, int CAP = 128>
 __device__ __forceinline__ void gemm_epilogue_linear_lds(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
-                                                         int stat_part, const float2* lnrow, const float* ev, int img0, char* stage_rows = nullptr) {
+                                                         int stat_part, const float2* lnrow, const float* ev, int img0) {
     const int nres = (p.res1 != nullptr) + (p.res2 != nullptr);  // kernel-uniform
     if constexpr (BN == 320) {  // MX-fp8 output tiles (BASELINE config 5; validate(): 320-column tiles, no residuals): their own instantiation,
         if (p.mx8_out != nullptr && n0 < p.mx8_cols) {  // so that the bf16 bodies carry none of its registers
@@ -581,7 +547,7 @@ __device__ __forceinline__ void gemm_epilogue_linear_lds(const VkGemmDesc& p, f3
             return;
         }
     }
-#define VK_EPI_BODY(NR, LNF) epilogue_linear_lds_body<NR, LNF, false, FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0, stage_rows)
+#define VK_EPI_BODY(NR, LNF) epilogue_linear_lds_body<NR, LNF, false, FX, FY, FM, FN, BN, CAP>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, lnrow, ev, img0)
     if (lnrow != nullptr) {
         if (nres == 0) VK_EPI_BODY(0, true);
         else if (nres == 1) VK_EPI_BODY(1, true);

@@ -358,16 +358,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr; q.act = 0;
             gemm_epilogue<EPI_LINEAR, true, PFX, PFY, 2, 5>(q, acc, m0, n0, e_wm, e_wn, e_l31, e_lh);
         } else if constexpr (EPI == EPI_GEGLU) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, lnp, epi_vec);
-        else {
-            // VkGemmDesc.tile_cfg bit 7 (pipe_launch, VISTA_EPI_ROWS): the output leaves as whole row segments through a wave-private piece of the
-            // dead stage buffers (gemm_common.h, stage_rows): every wave is past its last fragment read after this barrier
-            char* stage_rows = nullptr;
-            if (p.tile_cfg & 128) {
-                __syncthreads();
-                stage_rows = smem + e_wave * (2 * PSTAGE / 8);
-            }
-            gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0, stage_rows);
-        }
+        else gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0);
 #ifdef PIPE_TIMING
         unsigned long long tm_t2;
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_t2) :: "memory");
@@ -397,9 +388,6 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
     const int tilesN = d->N / PBN, tilesM = (d->m_end - d->m_begin + PBM - 1) / PBM;   // (the caller normalised the row range)
     const int ntiles = tilesM * tilesN;
     VkGemmDesc desc = *d;
-    static_assert(2 * PSTAGE / 8 >= 32 * epi_row_stride(160), "a wave's share of the dead stage buffers holds one staged 32-row block");
-    static const bool epi_rows = [] { const char* e = getenv("VISTA_EPI_ROWS"); return e && atoi(e) != 0; }();   // A/B hook (round 5)
-    if (EPI == EPI_LINEAR && ksplit == 1 && epi_rows && !desc.mx8_out) desc.tile_cfg |= 128;
     const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally
     if constexpr (EPI == EPI_LINEAR) {
         if (ksplit > 1) {   // K slices x tiles; the caller (gemm.hip) runs the finishing pass
