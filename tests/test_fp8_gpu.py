@@ -512,7 +512,7 @@ def test_unet_with_fp8_feedforward_vs_reference_golden():
         attention.FP8["feedforward"] = False
     e8, eb = rl(out, g["out"]), rl(base, g["out"])
     print(f"[parity] UNet tiny, fp8 FeedForward: rel-L2 {e8:.3e} vs reference (bf16 path {eb:.3e}; fp8 vs bf16 {rl(out, base):.3e})")
-    assert e8 <= 7e-2 and eb <= 2.5e-2
+    assert e8 <= 6.6e-2 and eb <= 2.5e-2   # measured 5.52e-2 (round 5, gpurun call 2) + 20 %
     attention.FP8["feedforward"] = attention.FP8["conv"] = True
     try:
         out_c = net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=g["T"]).float().cpu()
@@ -520,7 +520,7 @@ def test_unet_with_fp8_feedforward_vs_reference_golden():
         attention.FP8["feedforward"] = attention.FP8["conv"] = False
     e8c = rl(out_c, g["out"])
     print(f"[parity] UNet tiny, fp8 FeedForward + convolutions: rel-L2 {e8c:.3e} vs reference (vs bf16 {rl(out_c, base):.3e})")
-    assert torch.isfinite(out_c).all() and e8c <= 1e-1
+    assert torch.isfinite(out_c).all() and e8c <= 8.8e-2   # measured 7.33e-2 + 20 %
     again = net(x8, timesteps=ts, context=ctx, y=y, cond_mask=mask, num_frames=g["T"]).float().cpu()
     assert torch.equal(again, base), "switching fp8 off must restore the bf16 path bit for bit"
 
@@ -538,8 +538,8 @@ def _all_fp8_on():
 
 def test_unet_full_width_fp8_vs_reference_golden():
     """BASELINE config 5 on the SHIPPED 1.65 B-parameter configuration (full widths 320/640/1280, T=5, latent 16x32)
-    against the reference's own fp32 output (tests/golden/unet_full_t5.pt). Re-stated tolerance for fp8 e4m3 GEMM operands:
-    rel-L2 <= 8e-2, max|err| <= 1.5e-1 max|ref| (the bf16 path: <= 2.5e-2 / 8e-2, measured 1.2e-2). Measured with FeedForwards + ResBlock
+    against the reference's own fp32 output (tests/golden/unet_full_t5.pt). Re-stated tolerance for fp8 e4m3 GEMM operands (round 5, tightened to
+    what is measured + margin): rel-L2 <= 6e-2, max|err| <= 1.0e-1 max|ref| (the bf16 path: <= 2.5e-2 / 8e-2, measured 1.2e-2). Measured with FeedForwards + ResBlock
     convolutions in fp8: 6.1e-2 / 9.1e-2 -- the longer K-sums of the full widths average the e4m3 rounding only a little below the
     64-channel network's 7.4e-2, because the error is dominated by the ~190 fp8 GEMMs on residual branches, not by their width."""
     import json
@@ -563,7 +563,7 @@ def test_unet_full_width_fp8_vs_reference_golden():
         json.dump({"what": "unet_full_t5 golden, config 5 fp8", "rel_l2_fp8": e8, "max_rel_fp8": mx, "rel_l2_bf16": eb},
                   open(os.path.join(d, "parity_fp8_full_width.json"), "w"))
     assert torch.isfinite(out).all() and not torch.equal(out, base)
-    assert e8 <= 8e-2 and mx <= 1.5e-1 and eb <= 2.5e-2
+    assert e8 <= 6e-2 and mx <= 1.0e-1 and eb <= 2.5e-2   # measured 4.60e-2 / 6.8e-2 (rounds 4 and 5): the re-stated config-5 tolerance is 6e-2
     assert torch.equal(run(), base), "switching fp8 off must restore the bf16 path bit for bit"
     del net
     torch.cuda.empty_cache()
@@ -572,7 +572,7 @@ def test_unet_full_width_fp8_vs_reference_golden():
 def test_sampler_full_50_step_schedule_fp8_vs_oracle():
     """the whole 50-step EDM schedule with BASELINE config 5 switched on, next to the bf16 figure (8.2e-3), against the
     same CPU oracle run. Each Euler step contracts towards the denoised estimate, so the per-forward fp8 error (7e-2 on this 64-channel
-    network) does not accumulate linearly. Re-stated tolerance: rel-L2 <= 8e-2 end to end."""
+    network) does not accumulate linearly. Re-stated tolerance: rel-L2 <= 6e-2 end to end (measured 4.6e-2)."""
     import json
     import os
     import sys
@@ -587,4 +587,4 @@ def test_sampler_full_50_step_schedule_fp8_vs_oracle():
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
         json.dump({"steps": steps, "rel_l2_fp8": r}, open(os.path.join(d, "parity_50step_fp8.json"), "w"))
-    assert torch.isfinite(got).all() and r <= 8e-2 and torch.equal(got[0], w["cond_frame"][0])
+    assert torch.isfinite(got).all() and r <= 6e-2 and torch.equal(got[0], w["cond_frame"][0])   # measured 4.57e-2

@@ -10,9 +10,11 @@ case "$1" in
     src=${VISTA_REFERENCE:-/root/reference}
     mkdir -p "$dst/vwm/modules/diffusionmodules"
     cp "$src/vwm/util.py" "$dst/vwm/"
-    for f in denoiser.py denoiser_scaling.py denoiser_weighting.py discretizer.py guiders.py sampling.py sampling_utils.py wrappers.py util.py; do
+    # (round 5: + the network itself -- video_model / openaimodel / attention / video_attention -- for the reference's own fp16-autocast error)
+    for f in denoiser.py denoiser_scaling.py denoiser_weighting.py discretizer.py guiders.py sampling.py sampling_utils.py wrappers.py util.py video_model.py openaimodel.py; do
       [ -f "$src/vwm/modules/diffusionmodules/$f" ] && cp "$src/vwm/modules/diffusionmodules/$f" "$dst/vwm/modules/diffusionmodules/"
     done
+    cp "$src/vwm/modules/attention.py" "$src/vwm/modules/video_attention.py" "$dst/vwm/modules/"
     echo "staged under $dst: run with VISTA_REFERENCE=$dst" ;;
   clean) rm -rf "$dst" ;;
   *) echo "usage: $0 stage|clean"; exit 2 ;;
