@@ -184,6 +184,28 @@ def gemm_rooflines(ops, n_img, H, W):
         ("gemm_pipe_kernel[conv3x3,linear,256x320 pipelined] level-0 conv 320->320 @72x128", lambda: ops.conv3x3(x3, pw_conv, n_img, H, W),
          2.0 * M * C * 9 * C, 2.0 * M * C * 2, "mfma"),
     ]
+    # the level-0 q|k|v projection (folded LayerNorm, K = 320 -> N = 960: HBM-bound) and the level-1 FeedForward pieces
+    M1, C1 = n_img * (H // 2) * (W // 2), 640
+    x1 = rn(M1, C1).to(torch.bfloat16)
+    res1 = rn(M1, C1).to(torch.bfloat16)
+
+    class _LN:   # LayerNorm parameter container for the fold (ops._ln_tuple)
+        def __init__(self, c):
+            self.weight, self.bias, self.eps = 1.0 + 0.1 * rn(c), 0.1 * rn(c), 1e-5
+    pw_qkv = ops.pack_linear_cat([rn(C, C) * C ** -0.5 for _ in range(3)], ln=_LN(C))
+    st0 = ops.rowstats(x)
+    pw_geglu1 = ops.pack_geglu(rn(8 * C1, C1) * C1 ** -0.5, rn(8 * C1), ln=_LN(C1))
+    pw_ffo1 = ops.pack_linear(rn(C1, 4 * C1) * (4 * C1) ** -0.5, rn(C1))
+    st1 = ops.rowstats(x1)
+    cases += [
+        ("gemm_pipe_kernel[dense,linear,LayerNorm fold] level-0 q|k|v projection 460800x320->960", lambda: ops.linear(x, pw_qkv, ln=st0),
+         2.0 * M * 3 * C * C, M * C * 2 + M * 3 * C * 2 + M * 8.0, "hbm"),
+        ("gemm_pipe_kernel[dense,geglu,LayerNorm fold] level-1 GEGLU 115200x640->5120 (gated to 2560)", lambda: ops.linear(x1, pw_geglu1, ln=st1),
+         2.0 * M1 * 8 * C1 * C1, M1 * C1 * 2 + M1 * 4 * C1 * 2, "mfma"),
+        ("level-1 FeedForward as it runs (GEGLU GEMM + out-projection GEMM with residual and row sums; not fused at width 640)",
+         lambda: ops.linear(ops.linear(x1, pw_geglu1, ln=st1), pw_ffo1, res1=res1, emit_stats=True),
+         2.0 * M1 * 8 * C1 * C1 + 2.0 * M1 * 4 * C1 * C1, 3.0 * M1 * C1 * 2 + 2.0 * M1 * 4 * C1 * 2, "mfma"),
+    ]
     out = []
     for name, fn, flop, byts, bound in cases:
         for _ in range(2):
@@ -389,7 +411,8 @@ def main():
                     traffic_src = f"rocprofv3 PMC passes of the same kernel and shape, {name} (sha256 of csrc/attention.hip matches the loaded tree)"
                 else:
                     traffic_src = f"{name} was measured on another csrc/attention.hip (sha256 mismatch): traffic dropped, re-run tools/prof_pmc_attn.sh"
-        roofline = {"kernel": "level-0 spatial self-attention (vk_attn_spatial_qkv_log2_bf16)", "bound": "mfma", "achieved": ach,
+        roofline = {"kernel": "level-0 spatial self-attention, vk_attn_spatial_qkv_log2_bf16: attn_spatial_pipe_kernel<4> (software-pipelined zero-base form; "
+                              "VISTA_ATTN_PIPE=0 selects the round-4 attn_spatial_kernel<8,2>)", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": traffic,
                     "traffic_source": traffic_src,
                     "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop,
