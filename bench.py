@@ -114,6 +114,23 @@ def cpu_baseline(net, T, H, W, seed):
             "parity_rel_l2_hip_vs_oracle": parity}
 
 
+def attn_traffic_record(root):
+    """(bytes per level-0 attention launch | None, where it came from). The HBM bytes come from separate rocprofv3 PMC passes (they cannot share a
+    run with the timed region): the newest profiles/r*_attn_traffic.json, which is STAMPED with the sha256 of the csrc/attention.hip it was measured
+    on -- a kernel source that has changed since reports no traffic rather than stale bytes (tests/test_bench_launch_cpu.py pins both branches)."""
+    import glob
+    import hashlib
+    sha = hashlib.sha256(open(os.path.join(root, "vista_amd", "csrc", "attention.hip"), "rb").read()).hexdigest()
+    cands = sorted(glob.glob(os.path.join(root, "profiles", "r*_attn_traffic.json")))
+    if not cands:
+        return None, "no profiles/r*_attn_traffic.json"
+    rec = json.load(open(cands[-1]))
+    name = os.path.relpath(cands[-1], root)
+    if rec.get("attention_hip_sha256") == sha:
+        return rec["traffic_bytes_per_launch"], f"rocprofv3 PMC passes of the same kernel and shape, {name} (sha256 of csrc/attention.hip matches the loaded tree)"
+    return None, f"{name} was measured on another csrc/attention.hip (sha256 mismatch): traffic dropped, re-run tools/prof_r05.sh"
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` from a plain shell: become the launcher of N ranks (one per GPU) and relay their exit code."""
     s = socket.socket()
@@ -397,20 +414,7 @@ def main():
         # HBM bytes per launch come from separate rocprofv3 PMC passes (they cannot share a run with the timed region): the newest
         # profiles/r*_attn_traffic.json, which is STAMPED with the sha256 of the csrc/attention.hip it was measured on -- a kernel source that
         # has changed since reports no traffic rather than stale bytes
-        traffic, traffic_src = None, "no profiles/r*_attn_traffic.json"
-        if full and world == 1:
-            import glob
-            import hashlib
-            sha = hashlib.sha256(open(os.path.join(ROOT, "vista_amd", "csrc", "attention.hip"), "rb").read()).hexdigest()
-            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_attn_traffic.json")))
-            if cands:
-                rec = json.load(open(cands[-1]))
-                name = os.path.relpath(cands[-1], ROOT)
-                if rec.get("attention_hip_sha256") == sha:
-                    traffic = rec["traffic_bytes_per_launch"]
-                    traffic_src = f"rocprofv3 PMC passes of the same kernel and shape, {name} (sha256 of csrc/attention.hip matches the loaded tree)"
-                else:
-                    traffic_src = f"{name} was measured on another csrc/attention.hip (sha256 mismatch): traffic dropped, re-run tools/prof_pmc_attn.sh"
+        traffic, traffic_src = (None, "reduced configuration / multi-GPU run: no traffic figure") if not (full and world == 1) else attn_traffic_record(ROOT)
         roofline = {"kernel": "level-0 spatial self-attention, vk_attn_spatial_qkv_log2_bf16: attn_spatial_pipe_kernel<4> (software-pipelined zero-base form; "
                               "VISTA_ATTN_PIPE=0 selects the round-4 attn_spatial_kernel<8,2>)", "bound": "mfma", "achieved": ach,
                     "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / (MFMA_BF16_PEAK / 1e12), "traffic": traffic,

@@ -49,3 +49,26 @@ def test_bench_rejects_mismatched_world():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env, capture_output=True, text=True,
                        timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=3" in (r.stderr + r.stdout)
+
+
+def test_roofline_traffic_is_tied_to_the_kernel_source(tmp_path):
+    """bench.py reports `roofline.traffic` only from a PMC record stamped with the sha256 of the csrc/attention.hip that is in the
+    tree; the tracked record must match the tracked source (a kernel edit without a re-measurement / re-stamp fails HERE, not silently in the
+    driver's line), and a foreign record yields None."""
+    import hashlib
+    import json
+    import shutil
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    traffic, src = bench.attn_traffic_record(root)
+    assert isinstance(traffic, int) and 1.0e9 < traffic < 3.0e9, src       # 1.18 GB algorithmic; measured 1.5-1.6 GB
+    fake = tmp_path / "repo"
+    (fake / "vista_amd" / "csrc").mkdir(parents=True)
+    (fake / "profiles").mkdir()
+    shutil.copy(os.path.join(root, "vista_amd", "csrc", "attention.hip"), fake / "vista_amd" / "csrc" / "attention.hip")
+    with open(fake / "vista_amd" / "csrc" / "attention.hip", "a") as f:
+        f.write("// edited\n")
+    rec = {"attention_hip_sha256": hashlib.sha256(open(os.path.join(root, "vista_amd", "csrc", "attention.hip"), "rb").read()).hexdigest(), "traffic_bytes_per_launch": 123}
+    json.dump(rec, open(fake / "profiles" / "r09_attn_traffic.json", "w"))
+    t2, src2 = bench.attn_traffic_record(str(fake))
+    assert t2 is None and "mismatch" in src2
