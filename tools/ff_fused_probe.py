@@ -1,7 +1,9 @@
 """Fused FeedForward (vk_ff_fused_bf16) vs the two-kernel form (GEGLU GEMM + out-projection GEMM) at the level-0 BASELINE shape:
 correctness against a torch fp32 reference and against the two-kernel form, then interleaved timings, then (round-4 experiment) the
 two-kernel form run in row chunks small enough for the hidden activation to stay in the 256 MB Infinity Cache.
-usage: python tools/ff_fused_probe.py [--quick]"""
+usage: python tools/ff_fused_probe.py [--quick]
+(round 5: the timing variants -- ops.FF_FUSED_DBG 1 / 2 / 4 / 8 -- exist only in a library built with -DFF_TIMING, e.g.
+ hipcc ... -DFF_TIMING -c vista_amd/csrc/ff_fused.hip; the product library runs the one shipped instantiation whatever the value)"""
 import json
 import os
 import sys

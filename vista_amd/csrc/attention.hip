@@ -19,7 +19,10 @@
 //   time (16 x 32 cycles per wave and tile) and its VALU issue time (~150 instructions, 33 of them v_exp at ~2.7x a plain VALU op):
 //   ablations with the softmax or 3/4 of the MFMAs removed, the per-instruction issue rates and three software-pipelined variants
 //   (32-key sub-steps with the next scores / this tile's exponentials / the previous PV interleaved in one wave, 3-stage ring) are in
-//   profiles/r02_attn_ablation.txt -- the pipelined forms were correct and no faster, so the levers left are instruction counts:
+//   profiles/r02_attn_ablation.txt -- those pipelined forms (7 VALU per MFMA, one accumulator chain) were correct and no faster; round 5's
+//   attn_spatial_pipe_kernel below (5 fillers per MFMA, alternating accumulators, two workgroups per CU) is, and serves the long sequences
+//   made of whole 256-row blocks (levels 0 / 1). For this kernel -- every other length, and the pipelined kernel's fallback -- the levers are
+//   instruction counts:
 //     * no row-maximum tree on the fast path: exponentials are taken against the EXISTING base and the tile is validated afterwards
 //       through its row sums; a tile that fails is redone with a re-base (see "MAX-FREE FAST PATH" in the kernel)
 //     * row sums from the bf16-rounded probabilities, two per v_dot2c_f32_bf16

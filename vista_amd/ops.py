@@ -390,7 +390,7 @@ def rowstats(x):
 
 FF_FUSED_WIDTH, FF_FUSED_MAX_HIDDEN = 320, 1280
 FF_FUSED_DBG_BUF = None
-FF_FUSED_DBG = 0  # timing experiments only (tools/ff_fused_probe.py): see ff_fused.hip, DBG
+FF_FUSED_DBG = 0  # timing experiments only (tools/ff_fused_probe.py), honoured by a library built with -DFF_TIMING; the product build ignores it
 
 
 def ff_fused_ok(pw_in, pw_out):
