@@ -9,7 +9,9 @@ git archive "$rev" vista_amd/csrc include | tar -x -C "$tmp"
 objs=""
 for f in "$tmp"/vista_amd/csrc/*.hip; do
   o="$tmp/$(basename "$f" .hip).o"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I"$tmp/include" -I"$tmp/vista_amd/csrc" -c "$f" -o "$o" &
+  extra=""
+  case "$(basename "$f")" in ff_fused.hip|attention.hip) extra="-fno-slp-vectorize";; esac   # vista_amd/build.py EXTRA_FLAGS
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $extra -I"$tmp/include" -I"$tmp/vista_amd/csrc" -c "$f" -o "$o" &
   objs="$objs $o"
 done
 wait

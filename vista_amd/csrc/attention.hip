@@ -648,18 +648,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
         attn_spatial_body<NW, 2, true, true>(smem, logical, q, k, v, o, n_img, heads, S, ldq, ldk, ldo, 1.0f, RESCALE_THR, ldv);
         return;
     }
+    // Output: lane (l31, lh) holds d = 32 dd + 8 g + 4 lh + e of row l31. Swapping the upper half-wave's quad g with the lower half-wave's quad
+    // g + 1 (v_permlane32_swap) leaves the lower lane with the 8 contiguous d of quad g and the upper lane with those of quad g + 1: 16-byte
+    // stores, half as many (the store tail of an attention workgroup is issue-bound: MI355X_MICROARCH.md, cycle constants). ldo % 8 == 0 and a
+    // 16-byte aligned `o` are the launcher's conditions for this kernel.
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int qrow = qb * QB + (wave * 2 + b) * 32 + l31;
-        uint16_t* optr = o + ((size_t)img * S + qrow) * ldo + head * 64 + 4 * lh;
+        uint16_t* optr = o + ((size_t)img * S + qrow) * ldo + head * 64 + 8 * lh;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 w;
-                w.x = pack_bf16(oacc[b][d][4 * g + 0] * inv[b], oacc[b][d][4 * g + 1] * inv[b]);
-                w.y = pack_bf16(oacc[b][d][4 * g + 2] * inv[b], oacc[b][d][4 * g + 3] * inv[b]);
-                *(uint2*)(optr + 32 * d + 8 * g) = w;
+            for (int gp = 0; gp < 2; ++gp) {
+                uint2 qa, qb2;
+                qa.x = pack_bf16(oacc[b][d][8 * gp + 0] * inv[b], oacc[b][d][8 * gp + 1] * inv[b]);
+                qa.y = pack_bf16(oacc[b][d][8 * gp + 2] * inv[b], oacc[b][d][8 * gp + 3] * inv[b]);
+                qb2.x = pack_bf16(oacc[b][d][8 * gp + 4] * inv[b], oacc[b][d][8 * gp + 5] * inv[b]);
+                qb2.y = pack_bf16(oacc[b][d][8 * gp + 6] * inv[b], oacc[b][d][8 * gp + 7] * inv[b]);
+                const auto rx = __builtin_amdgcn_permlane32_swap(qa.x, qb2.x, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(qa.y, qb2.y, false, false);
+                *(uint4*)(optr + 32 * d + 16 * gp) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
             }
     }
 }
@@ -1293,7 +1301,7 @@ static int attn_spatial_launch(const void* q, const void* k, const void* vt, voi
     // VISTA_ATTN_PIPE: 0 = off (A/B hook), 1 = four waves x 64 rows, two workgroups per CU, 2 = four waves, one workgroup per CU (one wave per
     // SIMD), 3 = eight waves (two per SIMD in one workgroup).
     static const int pipe_mode = [] { const char* e = getenv("VISTA_ATTN_PIPE"); return e ? atoi(e) : 1; }();
-    if (pre && pipe_mode > 0 && S >= 2048 && (ldo % 4) == 0) {
+    if (pre && pipe_mode > 0 && S >= 2048 && (ldo % 8) == 0 && (((size_t)o) & 15) == 0) {
         const int rows = pipe_mode == 3 ? 512 : 256;
         if (S % rows == 0) {
             const long long nb = (long long)(S / rows) * n_img * heads;
