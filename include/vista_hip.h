@@ -78,6 +78,15 @@ typedef struct VkGemmDesc {
      *   launch would leave most of the chip idle (tiles mod 256 small), the whole rounds run on the 256x320 pipelined kernel and the remaining
      *   rows as a second launch of 128x160 tiles. EPI_LINEAR / EPI_GEGLU, no split-K. ---- */
     int32_t m_begin, m_end;
+    /* ---- GroupNorm statistics of the OUTPUT from the epilogue (ABI v6): the GroupNorm32 that follows a ResBlock convolution (openaimodel.py:195-199,
+     *   227-234; video_model.py:38-52) needs (sum, sum of squares) per image and group of N/32 channels; instead of a read pass of its own over the
+     *   tensor this GEMM is writing, the epilogue emits the stage-1 partials of vk_groupnorm_stats_bf16 -- one slot of 64 floats [32 sums | 32 sums of
+     *   squares] per 64 consecutive output rows, taken from the bf16-rounded values it stores, in a fixed order (bitwise reproducible) --
+     *   and vk_groupnorm_finalize_partials folds them per image group (nchunks = gn_rows / 64). Only launches for which vk_gemm_gnstat_fit() > 0
+     *   may set gnstat_out (vk_gemm_bf16 returns an error otherwise): EPI_LINEAR, bf16 out, CONV3X3 / TEMPORAL3 without halos, N = 320 / 640 / 1280,
+     *   gn_rows % 64 == 0, the whole row range, on the 256x320 pipelined kernel in one launch (no split-K). ---- */
+    float* gnstat_out;   /* f32 [M / 64][64] or NULL */
+    int32_t gn_rows;     /* output rows per image (H*W of the output) */
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
@@ -96,6 +105,10 @@ int vk_gemm_tile_choice(const VkGemmDesc* d);
  * the remaining rows as 128x160 tiles; VkGemmDesc.m_begin / m_end), 0 = a single launch; negative = the error vk_gemm_bf16 would return.
  * Pure host function, no launch. */
 int vk_gemm_tail_split(const VkGemmDesc* d);
+/* ABI v6: > 0 (= M / 64, the number of 64-float slots gnstat_out needs) when vk_gemm_bf16 would take `d` with gnstat_out set, 0 when this
+ * problem cannot emit GroupNorm statistics (the caller then runs vk_groupnorm_stats_bf16 as before); negative = the error vk_gemm_bf16 would
+ * return. Evaluated with d->gnstat_out ignored (the launcher's kernel choice does not depend on it). Pure host function, no launch. */
+int vk_gemm_gnstat_fit(const VkGemmDesc* d);
 
 /* fp8 (OCP e4m3) variant of the DENSE GEMM for the UNet's Linear / 1x1 projections (BASELINE.json config 5: "fp8 1x1
  * conv-as-GEMM path"; same reference call sites as vk_gemm_bf16's DENSE mode: attention.py:268-285,97-128, video_attention.py).
@@ -245,6 +258,11 @@ int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partial_ws, int32
                             int32_t frames_per_group, void* stream);
 int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img,
                             int32_t S, int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream);
+/* ABI v6: the second stage of vk_groupnorm_stats_bf16 on partials somebody else produced (VkGemmDesc.gnstat_out): `partial` is
+ * [n_img][nchunks][64] stage-1 slots (consumed: the fold of large groups works in place), `sums` [n_img/frames_per_group][64] as above.
+ * Followed by vk_groupnorm_apply_bf16 (after the all-reduce of `sums` in a pixel-sharded run) it replaces vk_groupnorm_silu_bf16 without the
+ * statistics pass over x. */
+int vk_groupnorm_finalize_partials(float* partial, float* sums, int32_t n_img, int32_t nchunks, int32_t frames_per_group, void* stream);
 
 /* LayerNorm over C of x[rows][C] (+ optional per-image pre-add vector):  u = x + addvec[row / rows_per_vec];
  * if sum_out: sum_out = u (bf16);  y = LN(u)*gamma + beta.

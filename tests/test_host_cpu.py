@@ -534,3 +534,56 @@ def test_gemm_tail_split_rule_is_pinned():
     assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, m_begin=256, m_end=full) == 256 + 1792 * 256   # 1799 tiles of a row range: 7 rounds + 7
     assert split(full, 320, 2880, amode=ops.AMODE_CONV3X3, Cin=320, H=72, W=128, m_begin=5, m_end=4) < 0      # bad range
     assert split(full, 960, 320, tile_cfg=0) == 0                                                      # not asked for: off by default
+
+
+def test_gnstat_fit_rule_is_pinned():
+    """vk_gemm_gnstat_fit (ABI v6): which launches can emit the GroupNorm statistics of their output from the epilogue (VkGemmDesc.gnstat_out) --
+    the ResBlock convolutions of levels 0-2 at the BASELINE window (the pipelined 256x320 kernel, one launch) -- and which cannot and keep the
+    statistics pass: split-K launches (level 3, one rank's deeper levels), fp32 output, two residuals, 144-row images, the tail-split option.
+    Host arithmetic only; the answer does not depend on gnstat_out itself (the buffer is sized from it before the pointer exists)."""
+    import ctypes as C
+    from vista_amd import _lib, ops
+    lib = _lib.load()
+    one = C.c_void_p(16)
+
+    def fit(n_img, H, W, Cin, N, amode=ops.AMODE_CONV3X3, **kw):
+        d = _lib.VkGemmDesc()
+        d.A = d.Wt = d.out = one
+        S = H * W
+        d.M, d.N, d.lda, d.ldc = n_img * S, N, Cin, N
+        d.amode, d.epi, d.alpha, d.Cin = amode, ops.EPI_LINEAR, 1.0, Cin
+        d.splitk_ws, d.splitk_ws_bytes = one, 160 << 20
+        if amode == ops.AMODE_CONV3X3:
+            d.K, d.H, d.Wd, d.Hout, d.Wout, d.stride, d.ups = 9 * Cin, H, W, H, W, 1, 1
+        elif amode == ops.AMODE_TEMPORAL3:
+            d.K, d.T, d.S = 3 * Cin, 25 if n_img % 25 == 0 else n_img, S
+        else:
+            d.K = Cin
+        d.gn_rows = S
+        for k, v in kw.items():
+            setattr(d, k, v)
+        a = lib.vk_gemm_gnstat_fit(C.byref(d))
+        d.gnstat_out = one
+        assert lib.vk_gemm_gnstat_fit(C.byref(d)) == a   # the pointer itself changes nothing
+        return a
+
+    t3 = ops.AMODE_TEMPORAL3
+    assert fit(50, 72, 128, 320, 320) == 50 * 9216 // 64           # level-0 ResBlock convolution
+    assert fit(50, 72, 128, 960, 320) == 7200                      # first convolution of an output block (concat input)
+    assert fit(50, 72, 128, 320, 320, res1=one, ld_res1=320) == 7200
+    assert fit(50, 36, 64, 640, 640) == 1800 and fit(50, 18, 32, 1280, 1280) == 450
+    assert fit(50, 72, 128, 320, 320, amode=t3) == 7200 and fit(50, 36, 64, 640, 640, amode=t3) == 1800 and fit(50, 18, 32, 1280, 1280, amode=t3) == 450
+    assert fit(50, 72, 128, 320, 320, amode=t3, res2=one, ld_res2=320, alpha=0.4, beta=1.0) == 7200   # temporal conv2 + blend
+    assert fit(7, 72, 128, 320, 320) == 7 * 144                    # one rank of an 8-GPU run: level 0 still one launch of 252 tiles
+    assert fit(50, 9, 16, 1280, 1280) == 0                         # level 3: 144 rows per image, and a split-K launch
+    assert fit(7, 36, 64, 640, 640) == 0 and fit(7, 18, 32, 1280, 1280) == 0   # one rank's deeper levels: split-K
+    assert fit(50, 72, 128, 320, 320, out_f32=1) == 0
+    assert fit(50, 72, 128, 320, 320, res1=one, ld_res1=320, res2=one, ld_res2=320) == 0
+    assert fit(50, 72, 128, 320, 320, act=1) == 0 and fit(50, 72, 128, 320, 320, rowstat_out=one) == 0
+    assert fit(50, 72, 128, 320, 960) == 0                         # 30-channel groups do not tile 160-column wave tiles
+    assert fit(50, 72, 128, 320, 320, amode=t3, halo_prev=one) == 0            # halo frames: the sixteen-wave kernel
+    assert fit(50, 72, 128, 320, 320, tile_cfg=64) == 0            # the tail-split option would hand the last rows to another kernel
+    assert fit(50, 72, 128, 320, 320, tile_cfg=4) == 0 and fit(3, 16, 16, 320, 320, tile_cfg=7) == 12  # forced variants
+    assert fit(50, 72, 128, 320, 320, m_begin=256, m_end=512) == 0
+    assert fit(50, 72, 128, 320, 320, amode=ops.AMODE_DENSE) == 0  # (dense producers are not built with the emitting bodies)
+    assert fit(50, 72, 128, 320, 320, gn_rows=0) == 0 and fit(50, 72, 128, 320, 320, gn_rows=9216 + 64) == 0

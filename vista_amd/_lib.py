@@ -36,10 +36,11 @@ class VkGemmDesc(C.Structure):
         ("rowstat_out", _vp), ("rowvec2", _vp), ("act", _i32),
         ("mx8_out", _vp), ("mx8_scales", _vp), ("mx8_cols", _i32), ("ld_mx8", _i32), ("ld_mx8s", _i32),
         ("m_begin", _i32), ("m_end", _i32),
+        ("gnstat_out", _vp), ("gn_rows", _i32),
     ]
 
 
-ABI_VERSION = 5  # vk_abi_version() of the library this table mirrors
+ABI_VERSION = 6  # vk_abi_version() of the library this table mirrors
 
 # name -> argtypes; every entry returns int. Must list every symbol include/vista_hip.h declares
 # (tests/test_abi.py checks the header against this table and against the built library).
@@ -48,6 +49,7 @@ SIGNATURES = {
     "vk_gemm_rowstat_parts": [C.POINTER(VkGemmDesc)],
     "vk_gemm_tile_choice": [C.POINTER(VkGemmDesc)],
     "vk_gemm_tail_split": [C.POINTER(VkGemmDesc)],
+    "vk_gemm_gnstat_fit": [C.POINTER(VkGemmDesc)],
     "vk_gemm_fp8": [C.POINTER(VkGemmDesc), _vp, _vp, _i32, _vp],
     "vk_gemm_fp8_mx": [C.POINTER(VkGemmDesc), C.POINTER(VkFp8Args), _vp],
     "vk_gemm_fp8_rowstat_parts": [C.POINTER(VkGemmDesc)],
@@ -67,6 +69,7 @@ SIGNATURES = {
     "vk_groupnorm_silu_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
     "vk_groupnorm_stats_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vk_groupnorm_apply_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
+    "vk_groupnorm_finalize_partials": [_vp, _vp, _i32, _i32, _i32, _vp],
     "vk_layernorm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_rowstats_bf16": [_vp, _vp, _i32, _i32, _i64, _vp],
     "vk_groupnorm_silu_cat_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],

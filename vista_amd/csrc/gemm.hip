@@ -41,6 +41,7 @@
 // gemm_pipe.hip: the eight-wave pipelined 256x320 variant (tile_cfg 7); fit = 1 when it takes the problem
 extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d);
 extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream, int ksplit);
+extern "C" int vk_gemm_pipe_gnstat_ok(const VkGemmDesc* d, int ksplit);
 
 namespace {
 
@@ -674,10 +675,27 @@ extern "C" int vk_gemm_tail_split(const VkGemmDesc* d) {
     return tail_split_row(&q, choose_tile(&q));
 }
 
+// ABI v6: can the launch vk_gemm_bf16 would make for `d` emit the GroupNorm statistics of its output (VkGemmDesc.gnstat_out)? The answer is formed
+// from the launcher's own decision chain (streaming kernel, tile choice, K slices, tail split) -- none of which reads gnstat_out, so the launch
+// that follows with the pointer set takes the same kernel; vk_gemm_bf16 re-checks and refuses rather than dropping the statistics.
+extern "C" int vk_gemm_gnstat_fit(const VkGemmDesc* d) {
+    const int rc = validate(d);
+    if (rc != VK_OK) return rc;
+    VkGemmDesc q = *d;
+    norm_row_range(q);
+    if (q.epi != EPI_LINEAR || q.out_f32 || (q.amode != AMODE_CONV3X3 && q.amode != AMODE_TEMPORAL3)) return 0;
+    if (q.m_begin == 0 && q.m_end == q.M && stream_fit(d)) return 0;
+    if ((q.tile_cfg & 7) == 6) q.tile_cfg &= ~7;
+    const TileChoice t = choose_tile(&q);
+    if (t.cfg != 7 || t.ksplit != 1 || tail_split_row(&q, t) != 0) return 0;
+    return vk_gemm_pipe_gnstat_ok(&q, 1) ? q.M / 64 : 0;
+}
+
 extern "C" int vk_gemm_bf16(const VkGemmDesc* d_in, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const int rc = validate(d_in);
     if (rc != VK_OK) return rc;
+    if (d_in->gnstat_out && vk_gemm_gnstat_fit(d_in) <= 0) return VK_EINVAL;   // (never a silent launch without the statistics the caller will read)
     VkGemmDesc dq = *d_in;
     norm_row_range(dq);   // m_end = M unless the caller asked for a row range (validate() checked it)
     if (dq.m_begin == 0 && dq.m_end == dq.M && stream_fit(d_in)) return vk_gemm_stream_launch(&dq, stream_);

@@ -406,6 +406,71 @@ __device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// GroupNorm statistics of the OUTPUT, emitted by the LINEAR epilogue of the eight-wave 256x320 kernel (VkGemmDesc.gnstat_out, ABI v6): the
+// stage-1 partial sums norm.hip's gn_stats_kernel would otherwise produce in a read pass of its own over the tensor this epilogue is writing
+// (GroupNorm32 of openaimodel.py:195-199,227-234 / video_model.py:38-52 on the output of the preceding convolution). A wave tile is 64 rows x
+// 160 columns = 64 tokens of ONE image (gn_rows % 64 == 0) x NG = 160 / CPG whole channel groups (CPG = N / 32 = 10, 20 or 40), so a wave owns
+// the slot [row block][its NG groups] of the partials outright: no atomics, a fixed summation order, bitwise reproducible.
+//   * accumulate (per lane, from the packed bf16 pairs it is about to store -- the values the apply pass will read): v_dot2_f32_bf16 with
+//     (1, 1) for the sum and with itself for the sum of squares, one accumulator pair per group. A lane's columns are 4 lh + {0..3} of every
+//     8: where a pair of the lower half-wave and the same pair of the upper half-wave fall into DIFFERENT groups (CPG = 10 only, 16 of a
+//     lane's 40 pairs per row block) the pair is masked by half-wave and added to both;
+//   * reduce over the 64 lanes (32 rows x 2 half-waves) as a transposing butterfly: v_permlane32_swap pairs value i with value i + NG (sums
+//     with sums of squares), then every xor step halves the register count by exchanging complementary halves, so the 2 NG values cost
+//     ~3 NG instructions instead of 12 NG, and end up one per lane (pair): lane L holds value 32 * (L >> 5) + gb + ((L & 31) >> SH) of the slot.
+template <int NG>
+__device__ __forceinline__ void gn_reduce_store(float (&gs)[NG], float (&gq)[NG], float* __restrict__ slot, int gb, int lane, bool valid) {
+    static_assert(NG == 16 || NG == 8 || NG == 4, "160-column wave tiles of 10 / 20 / 40-channel groups");
+    float r[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {   // lower half-wave: the pair total of sum i; upper half-wave: of sum-of-squares i
+        const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, gs[i]), __builtin_bit_cast(uint32_t, gq[i]), false, false);
+        r[i] = __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+    }
+    int k = 16;
+#pragma unroll
+    for (int n = NG; n > 1; n >>= 1, k >>= 1) {   // lanes with bit k clear keep registers [0, n/2) and hand over [n/2, n); the others the reverse
+        const bool up = (lane & k) != 0;
+#pragma unroll
+        for (int i = 0; i < n / 2; ++i) {
+            float lo = r[i], hi = r[i + n / 2];
+            asm volatile("" : "+v"(lo), "+v"(hi));   // two VALUES: left as array reads the selects become r[up ? i + n/2 : i], a 16-way v_cndmask chain each
+            const float keep = up ? hi : lo;
+            const float give = up ? lo : hi;
+            r[i] = keep + __shfl_xor(give, k, 64);
+        }
+    }
+#pragma unroll
+    for (; k >= 1; k >>= 1) r[0] += __shfl_xor(r[0], k, 64);
+    constexpr int SH = NG == 16 ? 1 : (NG == 8 ? 2 : 3);   // lanes per value inside a half-wave = 32 / NG
+    if (valid && (lane & ((1 << SH) - 1)) == 0) slot[32 * (lane >> 5) + gb + ((lane & 31) >> SH)] = r[0];
+}
+
+// the two pairs (columns c .. c+3, c = 32 fi + 8 g + 4 lh of the wave tile) of one packed quad into the group accumulators
+template <int CPG, int NG>
+__device__ __forceinline__ void gn_accumulate_quad(float (&gs)[NG], float (&gq)[NG], const int fi, const int g, const uint2 packed, const uint32_t lo_mask) {
+    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+    const bf2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t w = h ? packed.y : packed.x;
+        const int c0 = 32 * fi + 8 * g + 2 * h;                 // the pair's first column in a lane of the lower half-wave; + 4 in the upper one
+        const int G0 = c0 / CPG, G1 = (c0 + 4) / CPG;
+        if (G0 == G1) {
+            const bf2_t v = __builtin_bit_cast(bf2_t, w);
+            gs[G0] = __builtin_amdgcn_fdot2_f32_bf16(v, one, gs[G0], false);
+            gq[G0] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq[G0], false);
+        } else {   // the half-waves' pairs belong to different groups: each lane adds its pair to its own group and zeros to the other
+            const bf2_t v0 = __builtin_bit_cast(bf2_t, w & lo_mask), v1 = __builtin_bit_cast(bf2_t, w & ~lo_mask);
+            gs[G0] = __builtin_amdgcn_fdot2_f32_bf16(v0, one, gs[G0], false);
+            gq[G0] = __builtin_amdgcn_fdot2_f32_bf16(v0, v0, gq[G0], false);
+            gs[G1] = __builtin_amdgcn_fdot2_f32_bf16(v1, one, gs[G1], false);
+            gq[G1] = __builtin_amdgcn_fdot2_f32_bf16(v1, v1, gq[G1], false);
+        }
+    }
+}
+
 // LINEAR, unit by unit over the wave tile's U = FX*FY fragments (row block fj, column fragment fi): LayerNorm fold / bias / row vector from
 // LDS, + res1, * alpha, + beta * (res2 + rowvec2), bf16 pack, row sums, two 16-byte stores. The residuals are the only global loads, issued
 // as a RING that runs ahead of the stores: DA units' loads go out before the first unit is touched, and every finished unit -- its residual
@@ -414,12 +479,15 @@ __device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev
 // branch), because the sixteen-wave kernels live at the 128-VGPR cap with 64-80 accumulator registers: a residual that had to be spilled
 // would be WAITED for at the spill, which is exactly the serialisation this epilogue removes. Absent row vectors are staged as zeros and
 // added unconditionally (x + 0 is exact); the LayerNorm fold is a template flag (two more ds_reads and eight fmas per quad).
-template <int NRES, bool LN, bool MX, int FX, int FY, int FM, int FN, int BN, int CAP>
+template <int NRES, bool LN, bool MX, int FX, int FY, int FM, int FN, int BN, int CAP, int GNC = 0>
 __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
                                                          int stat_part, const float2* lnrow, const float* ev, int img0) {
     constexpr int MW = FM * 32, NW = FN * 32, U = FX * FY;
     // ring depth: what fits beside the accumulators (16 registers per unit), ~36 registers of addresses / per-quad temporaries and the
     // 128-VGPR cap, at 8 registers per unit and residual tensor
+    constexpr int GN_NG = GNC ? NW / GNC : 1;       // GNC = channels per GroupNorm group of the output when the epilogue emits its statistics (gnstat_out), else 0
+    // (the emitting bodies keep the same ring depth: their group accumulators come alive one fragment at a time while accumulator registers die
+    //  sixteen at a time -- each such kernel compiles to 231-244 VGPRs without scratch, checked with -Rpass-analysis=kernel-resource-usage)
     constexpr int ROOM = (CAP - 16 * U - 36) / 8;  // CAP: the kernel's VGPR budget (128 for sixteen waves, 256 for eight)
     constexpr int DA = NRES == 0 ? 0 : ((ROOM / NRES < 1 ? 1 : ROOM / NRES) < U ? (ROOM / NRES < 1 ? 1 : ROOM / NRES) : U);
     constexpr bool mx_tile = MX;  // this whole column tile is MX-fp8 output (the dispatcher checked n0 < mx8_cols; mx8_cols % BN == 0)
@@ -442,6 +510,13 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
         if (NRES == 2) rbo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ld_res2 + (uint32_t)wide_off) * 2u;
         oo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ldc + (uint32_t)(wide_off - (p.mx8_out ? p.mx8_cols : 0))) * 2u;  // (MX tiles never use it)
     }
+    static_assert(GNC == 0 || (MW == 64 && NW == 160 && NW % GNC == 0 && !MX), "gnstat_out: 64 x 160 wave tiles of whole channel groups");
+    float gs[GN_NG], gq[GN_NG];   // GNC: (sum, sum of squares) of the wave tile's GN_NG channel groups over its 64 rows, this lane's share
+    if constexpr (GNC != 0) {
+#pragma unroll
+        for (int i = 0; i < GN_NG; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+    }
+    const uint32_t gn_lo_mask = lh ? 0u : 0xffffffffu;
     uint4 wa[U][2], wb[U][2];
     auto issue = [&](int fj, int fi, int u) {
         if (NRES >= 1) { wa[u][0] = *(const uint4*)((const char*)ra + rao[fj] + fi * 64); wa[u][1] = *(const uint4*)((const char*)ra + rao[fj] + fi * 64 + 32); }
@@ -482,7 +557,7 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                 }
                 v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                if (p.act == 1) { v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]); }
+                if (GNC == 0 && p.act == 1) { v[0] = gelu_erf_f(v[0]); v[1] = gelu_erf_f(v[1]); v[2] = gelu_erf_f(v[2]); v[3] = gelu_erf_f(v[3]); }   // (no activation / row sums in the emitting bodies: vk_gemm_pipe_gnstat_ok)
                 if (NRES >= 1 && a_is_r1) {
                     const uint2 r = qa[g];
                     v[0] += bf16_lo(r.x); v[1] += bf16_hi(r.x); v[2] += bf16_lo(r.y); v[3] += bf16_hi(r.y);
@@ -497,11 +572,12 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
                 }
                 packed[g].x = pack_bf16(v[0], v[1]);
                 packed[g].y = pack_bf16(v[2], v[3]);
-                if (p.rowstat_out) {
+                if (GNC == 0 && p.rowstat_out) {
                     const float a0 = bf16_lo(packed[g].x), a1 = bf16_hi(packed[g].x), a2 = bf16_lo(packed[g].y), a3 = bf16_hi(packed[g].y);
                     ssum += (a0 + a1) + (a2 + a3);
                     qsum = fmaf(a0, a0, fmaf(a1, a1, fmaf(a2, a2, fmaf(a3, a3, qsum))));
                 }
+                if constexpr (GNC != 0) gn_accumulate_quad<GNC, GN_NG>(gs, gq, fi, g, packed[g], gn_lo_mask);
                 // one quad's vectors in flight at a time: left alone, the scheduler hoists every ds_read of the row block and spills the
                 // residuals it was told to keep in flight
                 __builtin_amdgcn_sched_barrier(0);
@@ -529,16 +605,27 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
             if (NRES >= 1 && u + DA < U) issue((u + DA) / FX, (u + DA) % FX, u + DA);  // this unit's residual registers are free again
             __builtin_amdgcn_sched_barrier(0);  // keep the order: this unit's stores, the next ring slot's loads, the next unit
         }
-        if (p.rowstat_out) {
+        if (GNC == 0 && p.rowstat_out) {
             const float so = __shfl_xor(ssum, 32, 64), qo = __shfl_xor(qsum, 32, 64);
             if (lh == 0 && row_ok[fj]) ((float2*)p.rowstat_out)[(size_t)stat_part * p.M + mrow[fj]] = make_float2(ssum + so, qsum + qo);
         }
     }
+    if constexpr (GNC != 0) {   // slot = the wave tile's 64-row block (M % 64 == 0: all of its rows are inside the problem, or none)
+        const int mb = m0 + wm * MW;
+        gn_reduce_store<GN_NG>(gs, gq, (float*)p.gnstat_out + (size_t)(mb >> 6) * 64, (n0 + wn * NW) / GNC, l31 | (lh << 5), mb < p.m_end);
+    }
 }
 
-template <int FX, int FY, int FM, int FN, int BN, int CAP = 128>
+// GN_CPG != 0: this kernel instantiation IS one of those that emit GroupNorm statistics of the output (VkGemmDesc.gnstat_out != NULL for every
+// launch of it: the pipelined kernel's CONV3X3 / TEMPORAL3 loaders, one tile per workgroup, no split-K) for groups of GN_CPG channels and GN_NRES
+// residual tensors, and carries that ONE body: two bodies behind a kernel-uniform branch already spill (40 bytes per lane), each alone takes 244 VGPRs
+template <int FX, int FY, int FM, int FN, int BN, int CAP = 128, int GN_CPG = 0, int GN_NRES = 0>
 __device__ __forceinline__ void gemm_epilogue_linear_lds(const VkGemmDesc& p, f32x16_t (&acc)[FX][FY], int m0, int n0, int wm, int wn, int l31, int lh,
                                                          int stat_part, const float2* lnrow, const float* ev, int img0) {
+    if constexpr (GN_CPG != 0) {   // (the launcher checked: N = 32 GN_CPG, GN_NRES residuals, no LayerNorm fold / MX output / activation / row sums)
+        epilogue_linear_lds_body<GN_NRES, false, false, FX, FY, FM, FN, BN, CAP, GN_CPG>(p, acc, m0, n0, wm, wn, l31, lh, stat_part, nullptr, ev, img0);
+        return;
+    }
     const int nres = (p.res1 != nullptr) + (p.res2 != nullptr);  // kernel-uniform
     if constexpr (BN == 320) {  // MX-fp8 output tiles (BASELINE config 5; validate(): 320-column tiles, no residuals): their own instantiation,
         if (p.mx8_out != nullptr && n0 < p.mx8_cols) {  // so that the bf16 bodies carry none of its registers

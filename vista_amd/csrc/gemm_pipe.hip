@@ -39,7 +39,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
 
-template <int AMODE, int EPI, bool NT_A, bool SPLIT>
+// GN_CPG != 0: an instantiation whose LINEAR epilogue also emits the GroupNorm statistics of the output (VkGemmDesc.gnstat_out, gemm_common.h) for
+// groups of GN_CPG channels with GN_NRES residual tensors; kernels of their own so that the others keep their register allocation, and one body
+// each (244 VGPRs, no scratch; any two bodies in one kernel spill)
+template <int AMODE, int EPI, bool NT_A, bool SPLIT, int GN_CPG = 0, int GN_NRES = 0>
 __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, const int ksplit) {
     constexpr int LN_OFF = 2 * PSTAGE, EV_OFF = LN_OFF + PBM * 8;
     constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr; q.act = 0;
             gemm_epilogue<EPI_LINEAR, true, PFX, PFY, 2, 5>(q, acc, m0, n0, e_wm, e_wn, e_l31, e_lh);
         } else if constexpr (EPI == EPI_GEGLU) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, lnp, epi_vec);
-        else gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0);
+        else gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256, GN_CPG, GN_NRES>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0);
 #ifdef PIPE_TIMING
         unsigned long long tm_t2;
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_t2) :: "memory");
@@ -403,6 +406,18 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
     // walk's first barrier (vmcnt(0)) of the next tile waits for every store of the last: measured -7..-10 % on the short-K level-0 / level-1
     // shapes, +-1 % on the deep-K ones (same-box sweep, profiles/r04_gemm_pipe.txt)
     const int grid = (EPI == EPI_GEGLU && ntiles > 256) ? 256 : ntiles;
+    if constexpr (EPI == EPI_LINEAR && AMODE != AMODE_DENSE) {
+        if (desc.gnstat_out) {   // (vk_gemm_pipe_launch checked vk_gemm_pipe_gnstat_ok: N = 320 / 640 / 1280, at most one residual tensor)
+            const int nres = (desc.res1 != nullptr) + (desc.res2 != nullptr);
+#define VK_PIPE_GN(CPG, NR) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false, false, CPG, NR>), dim3(grid), dim3(PNT), 0, stream, desc, 1)
+            if (desc.N == 320) { if (nres == 0) VK_PIPE_GN(10, 0); else VK_PIPE_GN(10, 1); }
+            else if (desc.N == 640) { if (nres == 0) VK_PIPE_GN(20, 0); else VK_PIPE_GN(20, 1); }
+            else { if (nres == 0) VK_PIPE_GN(40, 0); else VK_PIPE_GN(40, 1); }
+#undef VK_PIPE_GN
+            VK_CHECK_LAUNCH();
+            return VK_OK;
+        }
+    }
     if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, AMODE == AMODE_DENSE, false>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
     else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false, false>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
     VK_CHECK_LAUNCH();
@@ -431,10 +446,24 @@ extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d) {
     return 0;
 }
 
+// 1 = a launch of `d` on this kernel with `ksplit` K slices can emit the GroupNorm statistics of its output (VkGemmDesc.gnstat_out; d->gnstat_out
+// itself is not looked at: vk_gemm_gnstat_fit asks before the caller has a buffer). The epilogue's conditions: a wave tile = 64 rows of ONE
+// image x whole channel groups, every 64-row block entirely inside the problem, the finished accumulator in registers.
+extern "C" int vk_gemm_pipe_gnstat_ok(const VkGemmDesc* d, int ksplit) {
+    if (!vk_gemm_pipe_fit(d) || ksplit != 1 || d->epi != EPI_LINEAR || d->out_f32) return 0;
+    if (d->amode != AMODE_CONV3X3 && d->amode != AMODE_TEMPORAL3) return 0;   // (the instantiations built with the emitting bodies)
+    if (d->N != 320 && d->N != 640 && d->N != 1280) return 0;                 // 32 groups of 10 / 20 / 40 channels: 160-column wave tiles hold whole groups
+    if (d->ln_stats || d->mx8_out || d->act || d->rowstat_out || (d->res1 && d->res2)) return 0;   // (the emitting bodies: plain epilogue, at most one residual)
+    if (d->gn_rows <= 0 || (d->gn_rows % 64) != 0 || (d->M % d->gn_rows) != 0) return 0;
+    if (d->m_begin != 0 || (d->m_end != 0 && d->m_end != d->M)) return 0;     // (row ranges: the tail split would hand rows to another kernel)
+    return 1;
+}
+
 extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream_, int ksplit) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!vk_gemm_pipe_fit(d)) return VK_EINVAL;
     if (ksplit > 1 && (d->epi != EPI_LINEAR || !d->splitk_ws || d->ln_stats || d->rowstat_out || d->act)) return VK_EINVAL;
+    if (d->gnstat_out && !vk_gemm_pipe_gnstat_ok(d, ksplit)) return VK_EINVAL;
 #ifndef VK_PIPE_ONLY   // (-DVK_PIPE_ONLY=<amode>: a one-loader build for tuning sessions)
 #define VK_PIPE_ONLY -1
 #endif

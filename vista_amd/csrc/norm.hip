@@ -461,6 +461,24 @@ inline bool gn_geom(int n_img, int S, int C, int fpg, GnGeom& g) {
 }  // namespace
 
 namespace {
+// stage 2 of the statistics: sums[g][64] <- the nparts stage-1 slots of image group g, in a fixed order (one or two levels)
+int gn_finalize(float* partial_ws, float* sums, int ngroups, int nparts, hipStream_t stream) {
+    if (nparts <= 256) {
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(ngroups), dim3(256), 0, stream, partial_ws, sums, nparts, nparts, 0);
+    } else {
+        int per = 16;
+        while ((long long)per * per < nparts) per += 4;  // ~sqrt(nparts), a multiple of the 4 accumulation lanes
+        const int splits = (nparts + per - 1) / per;
+        // level 1: partial[g][k*per] <- sum of partial[g][k*per .. k*per+per)
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(ngroups, splits), dim3(256), 0, stream, partial_ws, sums, nparts, per, 1);
+        VK_CHECK_LAUNCH();
+        // level 2: sums[g] <- sum over the `splits` slots, which sit `per` partials apart (group stride = nparts partials)
+        hipLaunchKernelGGL(gn_finalize_level2_kernel, dim3(ngroups), dim3(256), 0, stream, (const float*)partial_ws, sums, nparts, per, splits);
+    }
+    VK_CHECK_LAUNCH();
+    return VK_OK;
+}
+
 int gn_stats(const void* x, const void* x2, int C1, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group,
              void* stream_, float* amax_part = nullptr) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -475,21 +493,7 @@ int gn_stats(const void* x, const void* x2, int C1, float* sums, float* partial_
         hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, partial_ws, S, C,
                            g.CG, g.R, g.tok, (float*)nullptr);
     VK_CHECK_LAUNCH();
-    const int nparts = frames_per_group * g.nchunks;
-    if (nparts <= 256) {
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(g.ngroups), dim3(256), 0, stream, partial_ws, sums, nparts, nparts, 0);
-    } else {
-        int per = 16;
-        while ((long long)per * per < nparts) per += 4;  // ~sqrt(nparts), a multiple of the 4 accumulation lanes
-        const int splits = (nparts + per - 1) / per;
-        // level 1: partial[g][k*per] <- sum of partial[g][k*per .. k*per+per)
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(g.ngroups, splits), dim3(256), 0, stream, partial_ws, sums, nparts, per, 1);
-        VK_CHECK_LAUNCH();
-        // level 2: sums[g] <- sum over the `splits` slots, which sit `per` partials apart (group stride = nparts partials)
-        hipLaunchKernelGGL(gn_finalize_level2_kernel, dim3(g.ngroups), dim3(256), 0, stream, (const float*)partial_ws, sums, nparts, per, splits);
-    }
-    VK_CHECK_LAUNCH();
-    return VK_OK;
+    return gn_finalize(partial_ws, sums, g.ngroups, frames_per_group * g.nchunks, stream);
 }
 
 int gn_apply(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img, int32_t S,
@@ -514,6 +518,13 @@ extern "C" int vk_groupnorm_stats_bf16(const void* x, float* sums, float* partia
 extern "C" int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img,
                                        int32_t S, int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream_) {
     return gn_apply(x, nullptr, 0, y, gamma, beta, sums, n_img, S, C, frames_per_group, count, eps, silu, stream_);
+}
+
+// ABI v6: stage 2 alone, on the stage-1 slots a GEMM epilogue wrote (VkGemmDesc.gnstat_out: one slot per 64 output rows)
+extern "C" int vk_groupnorm_finalize_partials(float* partial, float* sums, int32_t n_img, int32_t nchunks, int32_t frames_per_group, void* stream_) {
+    if (!partial || !sums || n_img <= 0 || nchunks <= 0 || frames_per_group <= 0 || (n_img % frames_per_group) != 0) return VK_EINVAL;
+    if ((long long)frames_per_group * nchunks > (1LL << 24)) return VK_EINVAL;
+    return gn_finalize(partial, sums, n_img / frames_per_group, frames_per_group * nchunks, (hipStream_t)stream_);
 }
 
 extern "C" int vk_groupnorm_silu_cat_bf16(const void* x1, const void* x2, void* y, const float* gamma, const float* beta, float* stats_ws,

@@ -28,11 +28,16 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
         tensors {"emb_silu": (B*T, E), "ctx": (B*T, ctx)} the pixel-sharded temporal halves need."""
         from ..video_attention import SpatialVideoTransformer
         from .video_model import VideoResBlock
-        for layer in self:
+        layers = list(self)
+        x_gn = None  # GroupNorm statistics of x, emitted by the convolution that produced it (ops.GnPartials), for the layer that opens with a norm of x
+        for i, layer in enumerate(layers):
             if isinstance(layer, VideoResBlock):
-                x = layer(x, emb_silu, num_frames, H, W, shard=shard, full=full)
+                # the block's last convolution (temporal conv2 + blend) emits the statistics of the transformer's opening GroupNorm
+                x_gn = ops.GnPartials() if i + 1 < len(layers) and isinstance(layers[i + 1], SpatialVideoTransformer) else None
+                x = layer(x, emb_silu, num_frames, H, W, shard=shard, full=full, out_gn=x_gn)
             elif isinstance(layer, SpatialVideoTransformer):
-                x = layer(x, context, frame_idx, num_frames, H, W, shard=shard, full=full)
+                x = layer(x, context, frame_idx, num_frames, H, W, shard=shard, full=full, x_gn=x_gn)
+                x_gn = None
             elif isinstance(layer, (Upsample, Downsample)):
                 x, H, W = layer(x, H, W)
             else:
@@ -127,14 +132,17 @@ class ResBlock(TimestepBlock, Packable):
             pk["conv2_8"] = pc8(self.out_layers[3].weight, self.out_layers[3].bias, device=dev)
         return pk
 
-    def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, shard=None, T_global=None):
+    def forward(self, x, emb_silu, H, W, T=None, out_alpha=1.0, shard=None, T_global=None, x_gn=None, out_gn=None):
         """x (n_img, S, C) bf16, or a pair (h, skip) standing for their channel concat (the `torch.cat([h, hs.pop()], dim=1)` of
         the UNet's output blocks, video_model.py:493, read in place by the norm and the 1x1 skip conv -- never materialised);
         emb_silu (n_img, emb_channels) bf16 = silu(emb).
         dims=2: returns skip(x) + h.  dims=3 (time_stack): statistics/conv span the T frames of each clip and the result is
         blend + out_alpha*(conv2 + bias) with blend = x, i.e. AlphaBlender(x_spatial=x, x_temporal=x+h) folded in.
         Multi-GPU (`shard`): x holds T = t_local frames of a T_global-frame clip; the norms all-reduce their partial sums and
-        the convs read the neighbour ranks' boundary frames (halo exchange)."""
+        the convs read the neighbour ranks' boundary frames (halo exchange).
+        x_gn / out_gn (ops.GnPartials or None): the GroupNorm statistics of x as its producer's epilogue emitted them (the first norm then runs
+        no statistics pass), and a holder the LAST convolution of this block fills with the statistics of the result for whoever norms it next;
+        the second norm always takes its statistics from the first convolution's epilogue when that launch can emit them (ops.GN_EPI)."""
         pk = self.packed()
         xb = None
         if isinstance(x, tuple):
@@ -155,12 +163,12 @@ class ResBlock(TimestepBlock, Packable):
         else:
             emb_out = ops.linear(emb_silu, pk["emb"], out_f32=True)
 
-        def gnorm(t, gn):
+        def gnorm(t, gn, part=None):
             if shard is None or self.dims == 2:
-                return ops.groupnorm(t, gn.weight, gn.bias, gn.eps, silu=True, frames_per_group=fpg)
+                return ops.groupnorm(t, gn.weight, gn.bias, gn.eps, silu=True, frames_per_group=fpg, gn=part)
             # frame-sharded temporal norm: statistics span (C/32, ALL T frames, H*W) -> all-reduce the local partial sums
             cnt = float(t.shape[-1] // 32) * float(S) * float(T_global)
-            return ops.groupnorm_sharded(t, gn.weight, gn.bias, gn.eps, True, fpg, shard.all_reduce_sum, cnt)
+            return ops.groupnorm_sharded(t, gn.weight, gn.bias, gn.eps, True, fpg, shard.all_reduce_sum, cnt, gn=part)
 
         def halo(t):
             return shard.halo_exchange(t) if (shard is not None and self.dims == 3) else (None, None)
@@ -179,12 +187,13 @@ class ResBlock(TimestepBlock, Packable):
             h = ops.conv_t3_fp8(h8, hs, pk["conv1_8"], T, S, rowvec=emb_out)
             h8, hs = ops.groupnorm_fp8(h, gn2.weight, gn2.bias, gn2.eps, True, fpg)
             return ops.conv_t3_fp8(h8, hs, pk["conv2_8"], T, S, alpha=out_alpha, res2=x, beta=1.0)
-        h = gnorm(x, gn1) if xb is None else ops.groupnorm_cat(x, xb, gn1.weight, gn1.bias, gn1.eps, silu=True)
+        h = gnorm(x, gn1, x_gn) if xb is None else ops.groupnorm_cat(x, xb, gn1.weight, gn1.bias, gn1.eps, silu=True)
+        mid_gn = ops.GnPartials()  # statistics of the first convolution's output, from its epilogue (stays empty when that launch cannot emit them)
         if self.dims == 2:
-            h, _, _ = ops.conv3x3(h, pk["conv1"], n_img, H, W, rowvec=emb_out)
-            h = ops.groupnorm(h, gn2.weight, gn2.bias, gn2.eps, silu=True)
+            h, _, _ = ops.conv3x3(h, pk["conv1"], n_img, H, W, rowvec=emb_out, gn=mid_gn)
+            h = ops.groupnorm(h, gn2.weight, gn2.bias, gn2.eps, silu=True, gn=mid_gn)
             skip = x if "skip" not in pk else ops.linear(x, pk["skip"], x2=xb)
-            out, _, _ = ops.conv3x3(h, pk["conv2"], n_img, H, W, res1=skip)
+            out, _, _ = ops.conv3x3(h, pk["conv2"], n_img, H, W, res1=skip, gn=out_gn)
             return out
         if self.full3d:  # 3x3x3 time_stack (VAE decoder with video_kernel_size=3); single-GPU only
             if shard is not None or emb_out is not None:
@@ -193,10 +202,10 @@ class ResBlock(TimestepBlock, Packable):
             h = gnorm(h, gn2)
             return ops.conv3d(h, pk["conv2"], T, H, W, alpha=out_alpha, res2=x, beta=1.0)
         prev, nxt = halo(h)
-        h = ops.conv_t3(h, pk["conv1"], T, S, rowvec=emb_out, halo_prev=prev, halo_next=nxt)
-        h = gnorm(h, gn2)
+        h = ops.conv_t3(h, pk["conv1"], T, S, rowvec=emb_out, halo_prev=prev, halo_next=nxt, gn=mid_gn)
+        h = gnorm(h, gn2, mid_gn)
         prev, nxt = halo(h)
-        return ops.conv_t3(h, pk["conv2"], T, S, alpha=out_alpha, res2=x, beta=1.0, halo_prev=prev, halo_next=nxt)
+        return ops.conv_t3(h, pk["conv2"], T, S, alpha=out_alpha, res2=x, beta=1.0, halo_prev=prev, halo_next=nxt, gn=out_gn)
 
 
 class Timestep(nn.Module):

@@ -201,7 +201,7 @@ class FusedLoop:
         from .. import attention as _att
         # ... including the module-level switches that decide WHICH kernels forward_tokens launches (bench.py's config-5 side figure and the
         # fp8 tests flip them in-process): a graph captured under other switches must not be replayed
-        switches = (tuple(sorted(_att.FP8.items())), _att.FF_FUSED, _att.QKV_SPLIT, _att.Q_LOG2, ops.TILE_CFG,
+        switches = (tuple(sorted(_att.FP8.items())), _att.FF_FUSED, _att.QKV_SPLIT, _att.Q_LOG2, ops.TILE_CFG, ops.GN_EPI,
                     None if self.unet_shard is None else getattr(self.unet_shard, "a2a_chunks", None))
         key = (tuple(net_in.shape), n_ts, tuple(self.ctx2.shape), tuple(self.y2.shape), tuple(self.mask2.shape), self.T, self.H, self.W,
                None if self.unet_shard is None else id(self.unet_shard), str(net_in.device), switches)

@@ -69,14 +69,18 @@ class VideoResBlock(ResBlock):
         pk["alpha"] = self.time_mixer.alpha_value()
         return pk
 
-    def forward(self, x, emb_silu, num_frames, H, W, shard=None, full=None):
-        x = super().forward(x, emb_silu, H, W)
+    def forward(self, x, emb_silu, num_frames, H, W, shard=None, full=None, out_gn=None):
+        """out_gn (ops.GnPartials or None): filled by the last temporal convolution with the GroupNorm statistics of the result (the opening
+        norm of the SpatialVideoTransformer that follows). The temporal ResBlock's own first norm takes its statistics from the epilogue of the
+        spatial ResBlock's last convolution in the same way."""
+        mid = ops.GnPartials()
+        x = super().forward(x, emb_silu, H, W, out_gn=mid)
         alpha = self.packed()["alpha"]
         # alpha*x + (1-alpha)*(x + h_t) == x + (1-alpha)*h_t, fused into the last temporal conv's epilogue
         if shard is None:
-            return self.time_stack(x, emb_silu, H, W, T=num_frames, out_alpha=1.0 - alpha)
+            return self.time_stack(x, emb_silu, H, W, T=num_frames, out_alpha=1.0 - alpha, x_gn=mid, out_gn=out_gn)
         # frame-sharded: the temporal ResBlock keeps this rank's frames (halo exchange + stats all-reduce inside)
-        return self.time_stack(x, emb_silu, H, W, T=shard.t_local, out_alpha=1.0 - alpha, shard=shard, T_global=num_frames)
+        return self.time_stack(x, emb_silu, H, W, T=shard.t_local, out_alpha=1.0 - alpha, shard=shard, T_global=num_frames, x_gn=mid, out_gn=out_gn)
 
 
 class VideoUNet(nn.Module, Packable):

@@ -135,7 +135,7 @@ class SpatialVideoTransformer(SpatialTransformer):
                 "tpe2": ops.pack_linear(self.time_pos_embed[2].weight, self.time_pos_embed[2].bias, dev),
                 "alpha": self.time_mixer.alpha_value()}
 
-    def forward(self, x, context, frame_idx, T, H, W, shard=None, full=None):
+    def forward(self, x, context, frame_idx, T, H, W, shard=None, full=None, x_gn=None):
         """x: (n_img, S, C) bf16 tokens; context: (n_img, ctx_width) bf16 (one token per image); frame_idx: (B*T,) f32 frame
         index of every image of the window (arange(T) repeated per clip, video_attention.py:270-271).
         Multi-GPU (`shard`): x / context hold this rank's frames; the temporal block runs pixel-sharded between two
@@ -143,7 +143,8 @@ class SpatialVideoTransformer(SpatialTransformer):
         pk = self.packed()
         n_img, S, C = x.shape
         x_in = x
-        h = ops.groupnorm(x, self.norm.weight, self.norm.bias, self.norm.eps, silu=False)
+        # (x_gn: the statistics of x from the epilogue of the temporal convolution that produced it, ops.GnPartials -- no statistics pass then)
+        h = ops.groupnorm(x, self.norm.weight, self.norm.bias, self.norm.eps, silu=False, gn=x_gn)
         h, st = ops.linear(h, pk["proj_in"], emit_stats=True)                      # (n_img*S, C) + row sums for norm1
         # Frame-position embedding time_pos_embed(sinusoid(frame_idx)) (video_attention.py:270-276): a function of the WEIGHTS and the frame
         # indices only. The UNet hands every forward the same frame_idx tensor (VideoUNet._frame_idx), so the rows are kept next to the packed

@@ -249,6 +249,44 @@ class RowStats:
 
 ROW_RANGE = None  # tests: (m_begin, m_end) -> the next GEMM calls compute only those output rows (VkGemmDesc.m_begin / m_end, ABI v5)
 
+# GroupNorm statistics from the producing convolution's epilogue (VkGemmDesc.gnstat_out, ABI v6): 1 = a conv3x3 / conv_t3 call that is handed a
+# GnPartials and whose launch can emit them (vk_gemm_gnstat_fit) does, and groupnorm(..., gn=...) then skips its statistics pass; 0 = the
+# three-launch GroupNorm everywhere (A/B hook, VISTA_GN_EPI). A launch-affecting switch: part of the hipGraph cache key (sampling.py).
+GN_EPI = int(os.environ.get("VISTA_GN_EPI", "1"))
+
+
+class GnPartials:
+    """Stage-1 GroupNorm partial sums of a tensor, written by the epilogue of the convolution that produced it: f32 [n_img * nchunks][64] =
+    [32 group sums | 32 group sums of squares] per 64 consecutive rows (include/vista_hip.h, VkGemmDesc.gnstat_out). `t` stays None when the
+    producer's launch could not emit them (split-K, a sixteen-wave tile, halo frames, rows per image not a multiple of 64 ...): the consumer
+    then runs its own statistics pass -- same result up to the summation order. Consumed by ONE groupnorm call (the fold works in place)."""
+
+    __slots__ = ("t", "nchunks", "rows", "C")
+
+    def __init__(self):
+        self.t, self.nchunks, self.rows, self.C = None, 0, 0, 0
+
+
+def _ask_gn(d, gn, rows_per_image, device):
+    """Before the launch: if this GEMM can emit the GroupNorm statistics of its output, give it the buffer."""
+    if gn is None or not GN_EPI:
+        return
+    d.gn_rows = int(rows_per_image)
+    d.tile_cfg = TILE_CFG
+    if ROW_RANGE is not None:
+        return
+    if SPLITK_WS_BYTES:   # (the launcher's split-K decision looks at the workspace: ask with what _gemm will set)
+        ws = _splitk_workspace(_stream())
+        d.splitk_ws, d.splitk_ws_bytes = _p(ws), ws.numel() * 4
+    slots = _lib.load().vk_gemm_gnstat_fit(C.byref(d))
+    if slots < 0:
+        raise _lib.VistaHipError(f"vk_gemm_gnstat_fit failed with code {slots}")
+    if slots > 0:
+        gn.t = torch.empty(slots * 64, dtype=F32, device=device)
+        gn.nchunks, gn.rows, gn.C = int(rows_per_image) // 64, d.M, d.N
+        d.gnstat_out = _p(gn.t)
+
+
 
 def _gemm(desc, emit_stats=False, device=None):
     lib = _lib.load()
@@ -435,7 +473,7 @@ def ff_fused(x, pw_in, pw_out, *, out=None, rowvec=None, rows_per_vec=0, res1=No
 
 
 def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, rowvec=None, res1=None, res2=None, alpha=1.0,
-            beta=0.0, asym_pad=False):
+            beta=0.0, asym_pad=False, gn=None):
     """3x3 conv, pad 1, over token-major x (n_img, H*W, Cin); `ups`=2 applies a nearest x2 upsample to the source
     on the fly (Upsample.forward, openaimodel.py:100-102); stride 2 = Downsample (openaimodel.py:136)."""
     _need(x, BF16, "x")
@@ -457,12 +495,13 @@ def conv3x3(x, pw, n_img, H, W, *, stride=1, ups=1, out=None, out_f32=False, row
     d.H, d.Wd, d.Cin, d.Hout, d.Wout, d.stride, d.ups = H, W, cin, Hout, Wout, stride, ups
     d.asym_pad = 1 if asym_pad else 0
     _fill_epilogue(d, pw, out, M, rowvec, Hout * Wout, res1, res2, alpha, beta)
+    _ask_gn(d, gn, Hout * Wout, x.device)   # gn: a GnPartials to fill with the GroupNorm statistics of `out` (the norm that follows this conv)
     _gemm(d)
     return (out.view(n_img, Hout * Wout, pw.N) if out.is_contiguous() else out), Hout, Wout
 
 
 def conv_t3(x, pw, T, S, *, out=None, out_f32=False, rowvec=None, res1=None, res2=None, alpha=1.0, beta=0.0, halo_prev=None,
-            halo_next=None):
+            halo_next=None, gn=None):
     """3x1x1 temporal conv, pad (1,0,0) (video_model.py:38-52) over x ((b t), S, C). halo_prev / halo_next: (clips, S, C) frames
     adjacent to the local frame range (frame-sharded multi-GPU); None = zero padding."""
     _need(x, BF16, "x")
@@ -485,6 +524,7 @@ def conv_t3(x, pw, T, S, *, out=None, out_f32=False, rowvec=None, res1=None, res
                 raise ValueError(f"{name}: expected contiguous (clips, S, C) = {(x.shape[0] // T, S, cin)}, got {tuple(h.shape)}")
             setattr(d, name, _p(h))
     _fill_epilogue(d, pw, out, M, rowvec, S, res1, res2, alpha, beta)
+    _ask_gn(d, gn, S, x.device)
     _gemm(d)
     return out.view(x.shape[0], S, pw.N)
 
@@ -859,14 +899,33 @@ def softmax_rows(x, out=None):
     return out
 
 
-def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None):
-    """x (n_img, S, C) bf16 contiguous."""
+def _gn_partials_ok(gn, n_img, S, Cc):
+    """The producer's partials describe exactly this tensor (and have not been consumed yet)."""
+    if gn is None or gn.t is None:
+        return False
+    if gn.rows != n_img * S or gn.C != Cc or gn.nchunks * 64 != S:
+        raise ValueError(f"GnPartials of a ({gn.rows} rows, {gn.C} channels, {gn.nchunks * 64} rows per image) tensor passed to a GroupNorm over ({n_img}, {S}, {Cc})")
+    return True
+
+
+def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None, gn=None):
+    """x (n_img, S, C) bf16 contiguous. gn: the GnPartials the producer of x filled (conv3x3 / conv_t3 (..., gn=...)): fold + apply, no
+    statistics pass over x."""
     _need(x, BF16, "x")
     if not x.is_contiguous():
         raise ValueError("groupnorm: x must be contiguous")
     n_img, S, Cc = x.shape
     if out is None:
         out = torch.empty_like(x)
+    if _gn_partials_ok(gn, n_img, S, Cc):
+        lib = _lib.load()
+        sums = torch.empty((n_img // frames_per_group) * 64, dtype=F32, device=x.device)
+        check(lib.vk_groupnorm_finalize_partials(_p(gn.t), _p(sums), n_img, gn.nchunks, frames_per_group, _stream()), "vk_groupnorm_finalize_partials")
+        gn.t = None   # consumed
+        count = float(Cc // 32) * float(S) * float(frames_per_group)
+        check(lib.vk_groupnorm_apply_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(sums), n_img, S, Cc, frames_per_group, count, float(eps),
+                                          1 if silu else 0, _stream()), "vk_groupnorm_apply_bf16")
+        return out
     ws = torch.empty(((n_img // frames_per_group) + n_img * ((S + 31) // 32)) * 64, dtype=F32, device=x.device)
     lib = _lib.load()
     check(lib.vk_groupnorm_silu_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(ws), n_img, S, Cc, frames_per_group, float(eps),
@@ -889,17 +948,22 @@ def groupnorm_cat(a, b, gamma, beta, eps, silu, frames_per_group=1):
     return out
 
 
-def groupnorm_sharded(x, gamma, beta, eps, silu, frames_per_group, allreduce, global_count):
+def groupnorm_sharded(x, gamma, beta, eps, silu, frames_per_group, allreduce, global_count, gn=None):
     """GroupNorm whose statistics also span other ranks' shards of the same images (pixel-sharded temporal ResBlock):
-    local fixed-order sums -> `allreduce(sums)` (in place, SUM over ranks) -> apply with the GLOBAL element count."""
+    local fixed-order sums -> `allreduce(sums)` (in place, SUM over ranks) -> apply with the GLOBAL element count.
+    gn: the producer's GnPartials of x (as groupnorm)."""
     _need(x, BF16, "x")
     n_img, S, Cc = x.shape
     out = torch.empty_like(x)
     ng = n_img // frames_per_group
     sums = torch.empty(ng * 64, dtype=F32, device=x.device)
-    part = torch.empty(n_img * ((S + 31) // 32) * 64, dtype=F32, device=x.device)
     lib = _lib.load()
-    check(lib.vk_groupnorm_stats_bf16(_p(x), _p(sums), _p(part), n_img, S, Cc, frames_per_group, _stream()), "vk_groupnorm_stats_bf16")
+    if _gn_partials_ok(gn, n_img, S, Cc):
+        check(lib.vk_groupnorm_finalize_partials(_p(gn.t), _p(sums), n_img, gn.nchunks, frames_per_group, _stream()), "vk_groupnorm_finalize_partials")
+        gn.t = None
+    else:
+        part = torch.empty(n_img * ((S + 31) // 32) * 64, dtype=F32, device=x.device)
+        check(lib.vk_groupnorm_stats_bf16(_p(x), _p(sums), _p(part), n_img, S, Cc, frames_per_group, _stream()), "vk_groupnorm_stats_bf16")
     allreduce(sums)
     check(lib.vk_groupnorm_apply_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(sums), n_img, S, Cc, frames_per_group, float(global_count),
                                       float(eps), 1 if silu else 0, _stream()), "vk_groupnorm_apply_bf16")
