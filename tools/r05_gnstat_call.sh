@@ -14,5 +14,5 @@ for r in 1 2; do for sw in 0 1; do
 done; done
 timeout 500 python -m pytest tests/test_blocks_gpu.py -q --timeout 400 > $O/tests_blocks.txt 2>&1; echo "blocks rc=$?" | tee -a $O/summary.txt
 tail -5 $O/tests_blocks.txt
-timeout 300 python -m pytest tests/test_kernels_gpu.py -q -k "groupnorm or conv or pipe or tail" --timeout 250 > $O/tests_kernels_subset.txt 2>&1; echo "kernels subset rc=$?" | tee -a $O/summary.txt
-tail -3 $O/tests_kernels_subset.txt
+
+

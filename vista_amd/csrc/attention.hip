@@ -672,6 +672,16 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
     }
 }
 
+// WIDE (default): 16-byte output stores (quad g of the upper half-wave swapped with quad g + 1 of the lower one, as the spatial kernels); needs
+// ldo % 8 == 0 and a 16-byte aligned `o`. WSYNC (measured, NOT the default): the V tile is wave-private, so the two workgroup barriers of an
+// iteration can be replaced by wave-local ordering (LDS executes a wave's instructions in order; the fences only pin the compiler).
+// VISTA_ATTN_T (launcher) selects: bit 0 = WSYNC, bit 1 = WIDE; bitwise the same results. Same box, alternated processes, ms per launch at
+// B = 2, T = 25 (tools/attn_t_ab.py, profiles/r05_attn_temporal_ab.txt):        level 0 (S 9216, 5 heads)   level 1 (2304, 10)   level 2 (576, 20)
+//   0  barriers, 8-byte stores (rounds 1-4 of this repository)                  0.3152  3.74 TB/s            0.1586               0.0856
+//   1  wave-local sync, 8-byte stores                                            0.3387-0.3799               0.1707               0.0936   (slower: the barriers keep a
+//   2  barriers, 16-byte stores  <- default                                      0.2830  4.17 TB/s            0.1441               0.0796    workgroup's four problems -- four
+//   3  wave-local sync, 16-byte stores                                           0.2858                       0.1456               0.0811    heads of one pixel -- in step)
+template <bool WSYNC, bool WIDE>
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o, int B, int T,
                                                             int S, int heads, int ld, int k_off, int v_off, int ldo,
                                                             float scale_log2, long long nprob, int iters) {
@@ -753,7 +763,13 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
             pf[J] = __builtin_bit_cast(bf16x8_t, v);
         }
 
-        __syncthreads();  // V tile visible (uniform trip count: every wave reaches this)
+        if (WSYNC) {   // V tile visible to the other lanes of THIS wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();  // V tile visible (uniform trip count: every wave reaches this)
+        }
 
         f32x16_t oacc[2];
 #pragma unroll
@@ -775,7 +791,22 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
                 oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v), pf[J], oacc[d], 0, 0, 0);
             }
         }
-        if (active && t_ok) {
+        if (WIDE) {   // (the swaps run in every lane; only the stores are predicated)
+            uint16_t* optr = o + (row0 + (size_t)(t_ok ? l31 : 0) * S) * ldo + head * 64 + 8 * lh;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint2 qa, qb;
+                    qa.x = pack_bf16(oacc[d][8 * gp + 0] * inv, oacc[d][8 * gp + 1] * inv);
+                    qa.y = pack_bf16(oacc[d][8 * gp + 2] * inv, oacc[d][8 * gp + 3] * inv);
+                    qb.x = pack_bf16(oacc[d][8 * gp + 4] * inv, oacc[d][8 * gp + 5] * inv);
+                    qb.y = pack_bf16(oacc[d][8 * gp + 6] * inv, oacc[d][8 * gp + 7] * inv);
+                    const auto rx = __builtin_amdgcn_permlane32_swap(qa.x, qb.x, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(qa.y, qb.y, false, false);
+                    if (active && t_ok) *(uint4*)(optr + 32 * d + 16 * gp) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                }
+        } else if (active && t_ok) {
             uint16_t* optr = o + (row0 + (size_t)l31 * S) * ldo + head * 64 + 4 * lh;
 #pragma unroll
             for (int d = 0; d < 2; ++d)
@@ -787,7 +818,13 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
                     *(uint2*)(optr + 32 * d + 8 * g) = w2;
                 }
         }
-        __syncthreads();  // LDS tile free for the next problem
+        if (WSYNC) {   // this wave's reads of its tile are done before its next writes (in-order LDS; compiler pinned)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();  // LDS tile free for the next problem
+        }
     }
 }
 
@@ -1362,8 +1399,16 @@ extern "C" int vk_attn_temporal_bf16(const void* qkv, void* o, int32_t B, int32_
     const long long cap = 256LL * 16;  // 16 workgroups per CU keeps plenty of loads in flight
     const int grid = (int)(want < cap ? want : cap);
     const int iters = (int)((want + grid - 1) / grid);
-    hipLaunchKernelGGL(attn_temporal_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)qkv, (uint16_t*)o, B, T,
-                       S, heads, ld, k_off, v_off, ldo, scale * LOG2E, nprob, iters);
+    static const int mode_env = [] { const char* e = getenv("VISTA_ATTN_T"); return e ? atoi(e) : 2; }();   // A/B hook: bit 0 = wave-local sync, bit 1 = 16-byte stores (default: measured below)
+    int mode = mode_env & 3;
+    if ((ldo % 8) != 0 || (((size_t)o) & 15) != 0) mode &= 1;   // 16-byte stores need 16-byte aligned rows
+#define VK_ATTN_T(WS, WD) hipLaunchKernelGGL((attn_temporal_kernel<WS, WD>), dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const uint16_t*)qkv, \
+                                             (uint16_t*)o, B, T, S, heads, ld, k_off, v_off, ldo, scale * LOG2E, nprob, iters)
+    if (mode == 3) VK_ATTN_T(true, true);
+    else if (mode == 2) VK_ATTN_T(false, true);
+    else if (mode == 1) VK_ATTN_T(true, false);
+    else VK_ATTN_T(false, false);
+#undef VK_ATTN_T
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
