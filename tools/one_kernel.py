@@ -1,5 +1,5 @@
 """Run ONE hot kernel at a BASELINE shape a few times (for rocprofv3 --pmc passes).
-usage: python tools/one_kernel.py {attn|conv|geglu|ffout|linear|ffused} [level 0|1|2]"""
+usage: python tools/one_kernel.py {attn|conv|convemb|convgn|geglu|ffout|linear|ffused} [level 0|1|2]"""
 import os
 import sys
 
@@ -27,6 +27,11 @@ elif kind == "conv":
     pc = ops.pack_conv3x3(torch.randn(C, C, 3, 3) * (9 * C) ** -0.5, torch.randn(C))
     x3 = x.view(N, S, C)
     fn = lambda: ops.conv3x3(x3, pc, N, H, W)  # noqa: E731
+elif kind in ("convemb", "convgn"):  # round 5: conv3x3 + per-image row vector, without / with the epilogue that also emits the GroupNorm statistics of the output
+    pc = ops.pack_conv3x3(torch.randn(C, C, 3, 3) * (9 * C) ** -0.5, torch.randn(C))
+    x3 = x.view(N, S, C)
+    rv = torch.randn(N, C, device="cuda")
+    fn = (lambda: ops.conv3x3(x3, pc, N, H, W, rowvec=rv, gn=ops.GnPartials())) if kind == "convgn" else (lambda: ops.conv3x3(x3, pc, N, H, W, rowvec=rv))  # noqa: E731
 elif kind == "geglu":
     pg = ops.pack_geglu(torch.randn(8 * C, C) * C ** -0.5, torch.randn(8 * C))
     fn = lambda: ops.linear(x, pg)  # noqa: E731
