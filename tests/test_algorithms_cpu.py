@@ -113,3 +113,66 @@ def test_mx_block_scale_rule_is_the_tightest_power_of_two():
     assert torch.isfinite(codes).all() and (codes >= 208).all() and (codes <= 448).all()
     byte = ex + 127
     assert (byte >= 0).all() and (byte <= 254).all()
+
+
+def test_epilogue_groupnorm_statistics_lane_algorithm():
+    """Lane-level emulation of csrc/gemm_common.h::gn_accumulate_quad / gn_reduce_store (GroupNorm statistics emitted by a convolution's
+    epilogue, ABI v6): one 64-row x 160-column wave tile, lane (l31, lh) holds columns 32 fi + 8 g + 4 lh + e of rows 32 fj + l31. Pins the
+    index arithmetic the GPU tests can only observe from outside: which pairs straddle two channel groups between the half-waves (10-channel
+    groups only), that the transposing butterfly (v_permlane32_swap, then xor 16 / 8 / 4 / 2 / 1 with complementary halves exchanged) leaves value
+    32 (L >> 5) + ((L & 31) >> SH) in lane L, and that every slot entry of the wave's groups is written exactly once."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    lanes = np.arange(64)
+    for CPG in (10, 20, 40):
+        NG = 160 // CPG
+        X = rng.standard_normal((64, 160))
+        gs, gq = np.zeros((64, NG)), np.zeros((64, NG))
+        straddles = 0
+        for lane in range(64):
+            l31, lh = lane & 31, lane >> 5
+            for fj in range(2):
+                for fi in range(5):
+                    for g in range(4):
+                        for h in range(2):
+                            c0 = 32 * fi + 8 * g + 2 * h
+                            G0, G1 = c0 // CPG, (c0 + 4) // CPG
+                            pair = X[32 * fj + l31, c0 + 4 * lh: c0 + 4 * lh + 2]
+                            if G0 == G1:
+                                gs[lane, G0] += pair.sum(); gq[lane, G0] += (pair ** 2).sum()
+                            else:   # masked by half-wave: the lane's pair goes to its own group, zeros to the other
+                                straddles += lane == 0 and fj == 0
+                                own = G0 if lh == 0 else G1
+                                gs[lane, own] += pair.sum(); gq[lane, own] += (pair ** 2).sum()
+        assert straddles == (16 if CPG == 10 else 0)
+
+        def swap32(a, b):   # v_permlane32_swap(vdst = a, src = b): a's upper half <-> b's lower half
+            a2, b2 = a.copy(), b.copy()
+            a2[32:], b2[:32] = b[:32], a[32:]
+            return a2, b2
+        r = []
+        for i in range(NG):
+            s0, s1 = swap32(gs[:, i], gq[:, i])
+            r.append(s0 + s1)
+        k, n = 16, NG
+        while n > 1:
+            up = (lanes & k) != 0
+            for i in range(n // 2):
+                keep, give = np.where(up, r[i + n // 2], r[i]), np.where(up, r[i], r[i + n // 2])
+                r[i] = keep + give[lanes ^ k]
+            n //= 2
+            k //= 2
+        while k >= 1:
+            r[0] = r[0] + r[0][lanes ^ k]
+            k //= 2
+        SH = {16: 1, 8: 2, 4: 3}[NG]
+        slot = np.full(64, np.nan)
+        for lane in range(64):
+            if lane & ((1 << SH) - 1) == 0:
+                e = 32 * (lane >> 5) + ((lane & 31) >> SH)
+                assert np.isnan(slot[e])
+                slot[e] = r[0][lane]
+        ref_s = X.reshape(64, NG, CPG).sum(axis=(0, 2))
+        ref_q = (X ** 2).reshape(64, NG, CPG).sum(axis=(0, 2))
+        assert np.allclose(slot[:NG], ref_s, rtol=1e-10, atol=1e-9) and np.allclose(slot[32:32 + NG], ref_q, rtol=1e-10)
+        assert np.isnan(slot[NG:32]).all() and np.isnan(slot[32 + NG:]).all()
