@@ -118,8 +118,8 @@ def test_mx_block_scale_rule_is_the_tightest_power_of_two():
 def test_epilogue_groupnorm_statistics_lane_algorithm():
     """Lane-level emulation of csrc/gemm_common.h::gn_accumulate_quad / gn_reduce_store (GroupNorm statistics emitted by a convolution's
     epilogue, ABI v6): one 64-row x 160-column wave tile, lane (l31, lh) holds columns 32 fi + 8 g + 4 lh + e of rows 32 fj + l31. Pins the
-    index arithmetic the GPU tests can only observe from outside: which pairs straddle two channel groups between the half-waves (10-channel
-    groups only), that the transposing butterfly (v_permlane32_swap, then xor 16 / 8 / 4 / 2 / 1 with complementary halves exchanged) leaves value
+    index arithmetic the GPU tests can only observe from outside: which pairs straddle two channel groups between the half-waves (16 of 40 with
+    10-channel groups, 8 with 20, none with 40), that the transposing butterfly (v_permlane32_swap, then xor 16 / 8 / 4 / 2 / 1 with complementary halves exchanged) leaves value
     32 (L >> 5) + ((L & 31) >> SH) in lane L, and that every slot entry of the wave's groups is written exactly once."""
     import numpy as np
     rng = np.random.default_rng(0)
@@ -144,7 +144,7 @@ def test_epilogue_groupnorm_statistics_lane_algorithm():
                                 straddles += lane == 0 and fj == 0
                                 own = G0 if lh == 0 else G1
                                 gs[lane, own] += pair.sum(); gq[lane, own] += (pair ** 2).sum()
-        assert straddles == (16 if CPG == 10 else 0)
+        assert straddles == {10: 16, 20: 8, 40: 0}[CPG]   # of a lane's 40 pairs per 32-row block
 
         def swap32(a, b):   # v_permlane32_swap(vdst = a, src = b): a's upper half <-> b's lower half
             a2, b2 = a.copy(), b.copy()

@@ -414,8 +414,8 @@ __device__ __forceinline__ void epi_stage_vectors(const VkGemmDesc& p, float* ev
 // the slot [row block][its NG groups] of the partials outright: no atomics, a fixed summation order, bitwise reproducible.
 //   * accumulate (per lane, from the packed bf16 pairs it is about to store -- the values the apply pass will read): v_dot2_f32_bf16 with
 //     (1, 1) for the sum and with itself for the sum of squares, one accumulator pair per group. A lane's columns are 4 lh + {0..3} of every
-//     8: where a pair of the lower half-wave and the same pair of the upper half-wave fall into DIFFERENT groups (CPG = 10 only, 16 of a
-//     lane's 40 pairs per row block) the pair is masked by half-wave and added to both;
+//     8: where a pair of the lower half-wave and the same pair of the upper half-wave fall into DIFFERENT groups (16 of a lane's 40 pairs per
+//     row block at CPG = 10, 8 at CPG = 20, none at 40) the pair is masked by half-wave and added to both;
 //   * reduce over the 64 lanes (32 rows x 2 half-waves) as a transposing butterfly: v_permlane32_swap pairs value i with value i + NG (sums
 //     with sums of squares), then every xor step halves the register count by exchanging complementary halves, so the 2 NG values cost
 //     ~3 NG instructions instead of 12 NG, and end up one per lane (pair): lane L holds value 32 * (L >> 5) + gb + ((L & 31) >> SH) of the slot.
