@@ -10,6 +10,8 @@
 //           per-chunk workspace, then a finalize launch produces mean / rstd -> bitwise reproducible results.
 //   apply : same ownership; per-channel scale/shift folded once into 16 registers, then a pure streaming pass
 //           y = silu(x*a + b).
+#include <stdlib.h>
+
 #include "common.h"
 #include "vista_hip.h"
 
@@ -140,6 +142,28 @@ __global__ void gn_finalize_level2_kernel(const float* __restrict__ partial, flo
     if (threadIdx.x < 64) sums[(size_t)blockIdx.x * 64 + v] = (red[0][v] + red[1][v]) + (red[2][v] + red[3][v]);
 }
 
+// 16-byte accesses with / without the non-temporal hint (A/B hook VISTA_GN_NT of the apply pass: bit 0 = loads, bit 1 = stores; same bytes either way)
+typedef unsigned gn_u32x4_t __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 gn_ld16(const uint16_t* p) {
+    if constexpr (NT) {
+        const gn_u32x4_t v = __builtin_nontemporal_load((const gn_u32x4_t*)p);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *(const uint4*)p;
+    }
+}
+template <bool NT>
+__device__ __forceinline__ void gn_st16(uint16_t* p, const uint4 v) {
+    if constexpr (NT) {
+        const gn_u32x4_t w = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(w, (gn_u32x4_t*)p);
+    } else {
+        *(uint4*)p = v;
+    }
+}
+
+template <bool NTL, bool NTS>
 __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1, uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ stats, int S, int C, int CG, int R,
                                 int frames_per_group, float inv_cnt, float eps, int do_silu, int tok_per_wg) {
@@ -169,7 +193,7 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
     for (; t + 3 * R < tok1; t += 4 * R) {  // 4 independent 16-B loads in flight per thread
         uint4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *(const uint4*)(xs + (size_t)(t + u * R) * ld);
+        for (int u = 0; u < 4; ++u) v[u] = gn_ld16<NTL>(xs + (size_t)(t + u * R) * ld);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float f[8];
@@ -179,11 +203,11 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
                 const float w = fmaf(f[e], a[e], b[e]);
                 f[e] = do_silu ? silu_f(w) : w;
             }
-            *(uint4*)(y + base + (size_t)(t + u * R) * C) = pack8(f);
+            gn_st16<NTS>(y + base + (size_t)(t + u * R) * C, pack8(f));
         }
     }
     for (; t < tok1; t += R) {
-        const uint4 v = *(const uint4*)(xs + (size_t)t * ld);
+        const uint4 v = gn_ld16<NTL>(xs + (size_t)t * ld);
         float f[8];
         unpack8(v, f);
 #pragma unroll
@@ -191,7 +215,7 @@ __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* 
             const float w = fmaf(f[e], a[e], b[e]);
             f[e] = do_silu ? silu_f(w) : w;
         }
-        *(uint4*)(y + base + (size_t)t * C) = pack8(f);
+        gn_st16<NTS>(y + base + (size_t)t * C, pack8(f));
     }
 }
 
@@ -503,8 +527,21 @@ int gn_apply(const void* x, const void* x2, int C1, void* y, const float* gamma,
     if (!x || !y || !gamma || !beta || !sums || count <= 0.f || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
     const int tok_per_wg = g.tok;
     dim3 grid(g.nchunks, n_img);
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, (uint16_t*)y, gamma, beta, sums,
-                       S, C, g.CG, g.R, frames_per_group, 1.f / count, eps, silu, tok_per_wg);
+    // Non-temporal hints for tensors that do not fit the 256 MiB Infinity Cache anyway (levels 0 and 1 at the BASELINE window: 295 / 147 MB): the
+    // input is dead after this pass and the output is too large to survive until its consumer, so neither should evict what the neighbouring
+    // kernels keep there. Same box, alternated processes (tools/gn_nt_ab.py, profiles/r05_gn_nontemporal_ab.txt): GroupNorm (statistics + fold +
+    // apply) 0.190 -> 0.149 ms at level 0, 0.082 -> 0.078 at level 1, unchanged at level 2; GroupNorm + the 3x3 convolution that reads it 0.958 ->
+    // 0.940 / 0.853 -> 0.843 / 0.783 -> 0.79 (level 2 fits the cache: no hint there); step 164.1 -> 163.6 ms. Bitwise the same output.
+    // VISTA_GN_NT = 0..3 forces (bit 0 = loads, bit 1 = stores) for an A/B; unset = the size rule.
+    static const int nt_env = [] { const char* e = getenv("VISTA_GN_NT"); return e ? atoi(e) & 3 : -1; }();
+    const int nt_mode = nt_env >= 0 ? nt_env : ((long long)n_img * S * C * 2 >= (96LL << 20) ? 3 : 0);
+#define VK_GN_APPLY(NL, NS) hipLaunchKernelGGL((gn_apply_kernel<NL, NS>), grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, (uint16_t*)y, \
+                                               gamma, beta, sums, S, C, g.CG, g.R, frames_per_group, 1.f / count, eps, silu, tok_per_wg)
+    if (nt_mode == 3) VK_GN_APPLY(true, true);
+    else if (nt_mode == 2) VK_GN_APPLY(false, true);
+    else if (nt_mode == 1) VK_GN_APPLY(true, false);
+    else VK_GN_APPLY(false, false);
+#undef VK_GN_APPLY
     VK_CHECK_LAUNCH();
     return VK_OK;
 }
