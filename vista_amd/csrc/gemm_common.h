@@ -32,6 +32,21 @@ __device__ __forceinline__ uint4 widen_pair(uint2 qa, uint2 qb) {
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
 
+// 16-byte output store of the LDS-staged epilogues. -DVK_EPI_NT_STORES=1 builds them with the non-temporal hint (an A/B build: tools/build_nt_variant.sh;
+// the GroupNorm apply pass gained 20 % from it on tensors that do not fit the Infinity Cache, profiles/r05_gn_nontemporal_ab.txt).
+#ifndef VK_EPI_NT_STORES
+#define VK_EPI_NT_STORES 0
+#endif
+__device__ __forceinline__ void epi_st16(void* p, const uint4 v) {
+#if VK_EPI_NT_STORES
+    typedef unsigned epi_u32x4_t __attribute__((ext_vector_type(4)));
+    const epi_u32x4_t w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, (epi_u32x4_t*)p);
+#else
+    *(uint4*)p = v;
+#endif
+}
+
 // The inverse, for loads: the lower lane read the 8 contiguous bf16 of quad g (its own 4 and its partner's 4), the upper lane those of
 // quad g+1; two swaps hand every lane its own 4 values of both quads.
 __device__ __forceinline__ void unwiden_pair(const uint4& w, uint2& qa, uint2& qb) {
@@ -598,8 +613,8 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
             } else {
                 const uint4 s0 = widen_pair(packed[0], packed[1]), s1 = widen_pair(packed[2], packed[3]);
                 if (row_ok[fj]) {
-                    *(uint4*)(outb + oo[fj] + fi * 64) = s0;
-                    *(uint4*)(outb + oo[fj] + fi * 64 + 32) = s1;
+                    epi_st16(outb + oo[fj] + fi * 64, s0);
+                    epi_st16(outb + oo[fj] + fi * 64 + 32, s1);
                 }
             }
             if (NRES >= 1 && u + DA < U) issue((u + DA) / FX, (u + DA) % FX, u + DA);  // this unit's residual registers are free again
@@ -686,7 +701,7 @@ __device__ __forceinline__ void gemm_epilogue_geglu_lds(const VkGemmDesc& p, f32
                 packed[g].y = pack_bf16(a[2] * gelu_erf_f(gt[2]), a[3] * gelu_erf_f(gt[3]));
             }
             const uint4 w = widen_pair(packed[0], packed[1]);
-            if (row_ok) *(uint4*)(op + fi * 16) = w;
+            if (row_ok) epi_st16(op + fi * 16, w);
         }
     }
 }
