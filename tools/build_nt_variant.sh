@@ -2,7 +2,7 @@
 # A/B build of libvista_hip.so whose LDS-staged GEMM epilogues store with the non-temporal hint (-DVK_EPI_NT_STORES=1):  tools/build_nt_variant.sh <out.so>
 # then VISTA_HIP_LIB=<out.so> python bench.py ... against the in-tree library on the same box. The .so is git-ignored.
 set -e
-root=$(cd "$(dirname "$0")/.." && pwd); out=$1; tmp=$(mktemp -d); objs=""
+root=$(cd "$(dirname "$0")/.." && pwd); out=$(realpath -m "$1"); tmp=$(mktemp -d); objs=""
 for f in "$root"/vista_amd/csrc/*.hip; do
   o="$tmp/$(basename "$f" .hip).o"; extra=""
   case "$(basename "$f")" in ff_fused.hip|attention.hip) extra="-fno-slp-vectorize";; esac
@@ -10,5 +10,6 @@ for f in "$root"/vista_amd/csrc/*.hip; do
   objs="$objs $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" $objs
+# link from inside the temp dir: the offload bundler drops its per-target intermediates into the cwd
+(cd "$tmp" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out" $objs)
 rm -rf "$tmp"; echo "$out"
