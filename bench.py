@@ -223,6 +223,54 @@ def gemm_rooflines(ops, n_img, H, W):
          lambda: ops.linear(ops.linear(x1, pw_geglu1, ln=st1), pw_ffo1, res1=res1, emit_stats=True),
          2.0 * M1 * 8 * C1 * C1 + 2.0 * M1 * 4 * C1 * C1, 3.0 * M1 * C1 * 2 + 2.0 * M1 * 4 * C1 * 2, "mfma"),
     ]
+    # the temporal ResBlock's 3x1x1 convolution at level 0 (video_model.py:38-52; K = 3 C = 960: shallow for the pipelined kernel)
+    pw_t3 = ops.pack_conv_t3(rn(C, C, 3, 1, 1) * (3 * C) ** -0.5, rn(C))
+    T = 25 if n_img % 25 == 0 else n_img
+    cases.append(("gemm_pipe_kernel[temporal3,linear,256x320 pipelined] level-0 temporal conv 3x1x1 320->320, T = 25 @72x128",
+                  lambda: ops.conv_t3(x3, pw_t3, T, H * W), 2.0 * M * 3 * C * C, 2.0 * M * C * 2, "mfma"))
+    return _time_cases(cases)
+
+
+def hbm_rooflines(ops, n_img, H, W):
+    """roofline entries of the two HBM-bound kernels the north-star names beside the attention (GroupNorm+SiLU, temporal attention), level-0 shapes
+    of the BASELINE config: algorithmic bytes (input read once + output written once, bf16) / HIP-event time / 8 TB/s."""
+    dev = "cuda"
+    C, S, heads = 320, H * W, 5
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(n_img, S, C, device=dev, generator=g).to(torch.bfloat16)
+    gam, bet = torch.randn(C, device=dev, generator=g), torch.randn(C, device=dev, generator=g)
+    T = 25 if n_img % 25 == 0 else n_img
+    B = n_img // T
+    qkv = torch.randn(n_img * S, 3 * C, device=dev, generator=g).to(torch.bfloat16)
+    nbytes = float(x.numel() * 2)
+    cases = [
+        ("GroupNorm(32)+SiLU level 0 (50 x 9216 x 320): gn_stats + gn_apply (the apply pass folds the statistics slots itself since round 6)",
+         lambda: ops.groupnorm(x, gam, bet, 1e-5, True), 10.0 * x.numel(), 3.0 * nbytes, "hbm"),   # statistics read + apply read + apply write
+        ("attn_temporal_kernel level 0: 92160 (pixel, head) problems of 25 x 25 x 64 (video_attention.py:116-127)",
+         lambda: ops.attn_temporal(qkv, B, T, S, heads), 4.0 * B * S * heads * T * T * 64, 4.0 * nbytes, "hbm"),   # q | k | v read + o written
+    ]
+    return _time_cases(cases)
+
+
+def fp16_side_figure(args):
+    import subprocess
+    env = dict(os.environ, VISTA_ACT_DTYPE="fp16")
+    env.pop("VISTA_HIP_LIB", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline", "--no-extras"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        d = json.loads(line)
+        return {"value": d["value"], "unit": "steps/s", "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                "attention_frac": (d.get("roofline") or {}).get("frac"),
+                "note": "same step, fp16 activations / weights (v_mfma_f32_32x32x16_f16; softmax numerators and V stay bf16), own process: "
+                        "VISTA_ACT_DTYPE=fp16 python bench.py; parity: tests/test_f16_gpu.py (full-width UNet within 6e-3 of the fp32 reference "
+                        "against the bf16 build's 1.2e-2)"}
+    except Exception as e:  # noqa: BLE001 -- a side figure never takes the headline line down
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def _time_cases(cases):
     out = []
     for name, fn, flop, byts, bound in cases:
         for _ in range(2):
@@ -422,17 +470,19 @@ def main():
                     "launches_timed": len(l0), "avg_ms": avg_ms, "flop_per_launch": flop,
                     "timed_on": "HIP events on the launch stream around each level-0 launch of up to two extra steps of the same window, immediately after the timed region"}
 
+    act_name = "fp16" if _lib.ACT_DTYPE == "fp16" else "bf16"   # the 16-bit storage type of this process (VISTA_ACT_DTYPE; default bf16 = BASELINE config 2's)
+
     def layout(sh):
         return (("CFG-split x2 x " if sh.cfg_half is not None else "") + "frame-sharded " + "/".join(str(c) for c in sh.t_counts)) if sh else "single GPU"
     res = {
         "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": (("bf16 + fp8(e4m3) ResBlock convolutions, FeedForward GEMMs from width 640 up" + ("" if args.fp8_no_attn else ", attention QK^T, attention-out projections from width 640 up") + " [config 5]") if args.fp8 else
-                  "bf16 + fp8(e4m3) FeedForward GEMMs [config 5, FeedForward only]" if args.fp8_ff else "bf16"),
+                  "bf16 + fp8(e4m3) FeedForward GEMMs [config 5, FeedForward only]" if args.fp8_ff else act_name),
         "data": "synthetic" if backend == "nccl" or world == 1 else "synthetic (DRY RUN: gloo host-staged transport, ranks share one GPU -- not a result)",
         "config": {"workload": (f"{world}xMI355X " + layout(shard) +
                                 ": 25x576x1024 (latent 25x4x72x128), 50-step EulerEDM, VanillaCFG 2.5 (N=50 images per UNet call), "
-                                "bf16, random-init 1.65B VideoUNet, synthetic latents") if full else
+                                f"{act_name}, random-init 1.65B VideoUNet, synthetic latents") if full else
                    f"REDUCED (not the BASELINE config): T={T} latent {H}x{W} model_channels={args.model_channels}, {world} rank(s) " + layout(shard),
                    "frames": T, "latent": [4, H, W], "cfg_images_per_call": 2 * T, "sampler": "EulerEDM s_churn=0, 50-step schedule",
                    "t_counts": shard.t_counts if shard else [T], "shard": main_key,
@@ -476,6 +526,7 @@ def main():
                                           "note": "IdentityGuider: one UNet forward on N=25 images per step (half the CFG work), generic sampler path"}
             if full:
                 res["roofline_gemm"] = gemm_rooflines(ops, 2 * T, H, W)
+                res["roofline_hbm"] = hbm_rooflines(ops, 2 * T, H, W)
             if full and not (args.fp8 or args.fp8_ff):
                 # BASELINE config 5 as a side figure of the default (bf16) line: the same step with FeedForward GEMMs, ResBlock convolutions, the
                 # attention score product and the attention-out projection in fp8 e4m3; the fp8 weight packs are built during the
@@ -491,6 +542,10 @@ def main():
                                                   "parity: tests/test_fp8_gpu.py, tests/test_blocks_gpu.py"}
                 finally:
                     _att.FP8.update(saved)
+            if full and not (args.fp8 or args.fp8_ff) and _lib.ACT_DTYPE == "bf16":
+                # The fp16-storage build (libvista_hip_f16.so: the reference's own autocast width, sample_utils.py:301-303) as a side
+                # figure: the same step in a process of its own (the storage type is fixed per process). Never `value`: BASELINE config 2 names bf16.
+                res["fp16_storage"] = fp16_side_figure(args)
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         res["cpu_baseline"] = cpu_baseline(net, T, H, W, seed=1) if full else None
     else:

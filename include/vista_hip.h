@@ -87,6 +87,11 @@ typedef struct VkGemmDesc {
      *   gn_rows % 64 == 0, the whole row range, on the 256x320 pipelined kernel in one launch (no split-K). ---- */
     float* gnstat_out;   /* f32 [M / 64][64] or NULL */
     int32_t gn_rows;     /* output rows per image (H*W of the output) */
+    /* ---- fp16 storage build only (ABI v7; libvista_hip_f16.so, vk_act_dtype() == 1; the bf16 build ignores it): output columns n >= alt_cols_from
+     *   of an EPI_LINEAR 16-bit-out launch are written as bf16 instead of fp16. 0 = none; a multiple of 32. The V column block of the fused q|k|v
+     *   projections (attention.py:344-346): the attention kernels keep the P.V product in bf16 in both builds (their zero-base softmax needs bf16's
+     *   exponent range for the numerators), so V must arrive as bf16 while q and k are fp16. No row sums / GroupNorm statistics on such a launch. ---- */
+    int32_t alt_cols_from;
 } VkGemmDesc;
 
 /* nn.Linear / nn.Conv2d / nn.Conv3d call sites of the UNet:
@@ -263,6 +268,15 @@ int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamma, const fl
  * Followed by vk_groupnorm_apply_bf16 (after the all-reduce of `sums` in a pixel-sharded run) it replaces vk_groupnorm_silu_bf16 without the
  * statistics pass over x. */
 int vk_groupnorm_finalize_partials(float* partial, float* sums, int32_t n_img, int32_t nchunks, int32_t frames_per_group, void* stream);
+/* ABI v7: the apply pass straight on stage-1 slots (`partial` as above, NOT consumed): every workgroup folds its image group's
+ * frames_per_group * nchunks slots itself, in gn_finalize's summation order, so the output is bitwise that of vk_groupnorm_finalize_partials +
+ * vk_groupnorm_apply_bf16 with one launch less (GroupNorm32 of openaimodel.py:195-199,227-234 = producer epilogue + ONE pass). Taken when
+ * frames_per_group * nchunks <= vk_groupnorm_fold_max() (256; 0 when VISTA_GN_FOLD=0), else VK_EINVAL. Not for pixel-sharded norms (their raw
+ * sums are all-reduced between the two stages). vk_groupnorm_silu_bf16 / _cat_bf16 apply the same rule to their own statistics pass. */
+int vk_groupnorm_fold_max(void);
+int vk_groupnorm_apply_partials_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* partial, int32_t n_img,
+                                     int32_t S, int32_t C, int32_t nchunks, int32_t frames_per_group, float count, float eps, int32_t silu,
+                                     void* stream);
 
 /* LayerNorm over C of x[rows][C] (+ optional per-image pre-add vector):  u = x + addvec[row / rows_per_vec];
  * if sum_out: sum_out = u (bf16);  y = LN(u)*gamma + beta.
@@ -351,6 +365,11 @@ int vk_ensemble_variance_sum(const float* x, double* out, double* partial_ws, in
 
 /* library info */
 int vk_abi_version(void);
+/* ABI v7: the 16-bit storage type this library was built for: 0 = bf16 (libvista_hip.so, the default and the BASELINE config's dtype), 1 = IEEE fp16
+ * (libvista_hip_f16.so, -DVK_F16=1: the reference's autocast width, sample_utils.py:301-303). Every "bf16" in the entry-point names and comments of
+ * this header reads "the storage type" for the fp16 build; fp32 interfaces are unchanged. The fp8 entry points (BASELINE config 5) exist in the bf16
+ * build only and return VK_EINVAL in the other. */
+int vk_act_dtype(void);
 
 #ifdef __cplusplus
 }

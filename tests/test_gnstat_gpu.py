@@ -252,3 +252,39 @@ def test_video_resblock_and_transformer_same_result_with_and_without_epilogue_st
     assert first <= 1e-4, f"the first GroupNorm fed from partials differs by {first:.3g} relative from the three-launch form on the same input"
     d_paths, d_sens = rel(runs["epi"][0], runs["pass"][0]), rel(runs["perturbed"][0], runs["pass"][0])
     assert d_paths <= 2.0 * d_sens + 1e-4, f"block output moved by {d_paths:.3g} between the two statistics paths; a one-ulp perturbation of 0.1 % of the input moves it by {d_sens:.3g}"
+
+
+@pytest.mark.parametrize("n,S,Cc,fpg", [(4, 9216, 320, 1), (3, 2304, 640, 1), (5, 576, 1280, 1), (5, 144, 1280, 5), (10, 576, 1280, 5),
+                                        (6, 130, 320, 3), (2, 72, 2560, 1), (50, 144, 1280, 25)])
+def test_groupnorm_apply_folds_its_own_partials_bitwise(n, S, Cc, fpg):
+    """ABI v7: the apply pass that folds the stage-1 slots itself (vk_groupnorm_silu_bf16 when frames_per_group * chunks <= vk_groupnorm_fold_max(),
+    vk_groupnorm_apply_partials_bf16 on a convolution epilogue's slots) against the explicit stats -> finalize -> apply launches: bitwise equal."""
+    from vista_amd import _lib
+    ops = _ops()
+    lib = _lib.load()
+    assert lib.vk_groupnorm_fold_max() == 256
+    x = rnd(n, S, Cc, seed=3)
+    g, b = torch.randn(Cc, device="cuda"), torch.randn(Cc, device="cuda")
+    got = ops.groupnorm(x, g, b, 1e-5, True, frames_per_group=fpg)          # folds when it may
+    sums = stats_pass(ops, x, fpg).reshape(-1)
+    want = torch.empty_like(x)
+    count = float(Cc // 32) * S * fpg
+    _lib.check(lib.vk_groupnorm_apply_bf16(ops._p(x), ops._p(want), ops._p(g), ops._p(b), ops._p(sums), n, S, Cc, fpg, count, 1e-5, 1, ops._stream()),
+               "vk_groupnorm_apply_bf16")
+    assert torch.equal(got, want)
+    if S % 64 == 0:   # slots in the epilogue's geometry (one per 64 rows), here produced by summing the tensor on the host side of the test
+        xf = x.float().view(n, S // 64, 64, 32, Cc // 32)
+        part = torch.cat([xf.sum((2, 4)), (xf * xf).sum((2, 4))], -1).contiguous()   # [n][S/64][64]
+        nch = S // 64
+        out2 = torch.empty_like(x)
+        rc = lib.vk_groupnorm_apply_partials_bf16(ops._p(x), ops._p(out2), ops._p(g), ops._p(b), ops._p(part), n, S, Cc, nch, fpg, count, 1e-5, 1, ops._stream())
+        if fpg * nch > 256:
+            assert rc == -22
+        else:
+            assert rc == 0
+            s2 = torch.empty((n // fpg) * 64, dtype=F32, device="cuda")
+            _lib.check(lib.vk_groupnorm_finalize_partials(ops._p(part.clone()), ops._p(s2), n, nch, fpg, ops._stream()), "vk_groupnorm_finalize_partials")
+            want2 = torch.empty_like(x)
+            _lib.check(lib.vk_groupnorm_apply_bf16(ops._p(x), ops._p(want2), ops._p(g), ops._p(b), ops._p(s2), n, S, Cc, fpg, count, 1e-5, 1, ops._stream()),
+                       "vk_groupnorm_apply_bf16")
+            assert torch.equal(out2, want2)

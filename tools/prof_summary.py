@@ -29,6 +29,29 @@ def short(name):
     return m.group(1) if m else name[:60]
 
 
+def family(name):
+    """(table, label) of a kernel whose launches are split by geometry: the attention kernels (the roofline kernel is the level-0 launch of
+    attn_spatial_pipe_kernel: the largest grid) and the whole GEMM family (tiled, pipelined, streaming, fused FeedForward)."""
+    m = re.search(r"(attn_spatial_pipe_kernel|attn_spatial_kernel|attn_spatial_fp8qk_kernel|attn_temporal_kernel)<[^>]*>", name)
+    if m:
+        return "attn", m.group(0)
+    m = re.search(r"(gemm_pipe_kernel|gemm_pipe2_kernel|gemm_stream_kernel|ff_fused_kernel|gemm_fp8_kernel)<([^>]*)>", name)
+    if m:
+        return "gemm", f"{m.group(1)}<{m.group(2).replace(' ', '')}>"
+    if "gemm_kernel" in name:
+        return "gemm", short(name)
+    return None
+
+
+def print_geometry(attn, gemm):
+    print("\nattention kernels by launch geometry (grid_x = threads; the level-0 spatial launch is the largest grid):")
+    for (n, gx, wx), (c, t) in sorted(attn.items(), key=lambda kv: -kv[1][1]):
+        print(f"  {n:44s} wgs {gx // wx:6d} x {wx:4d}  calls {c:4d}  avg_us {t/c/1e3:9.2f}  total_ms {t/1e6:8.2f}")
+    print("\nGEMM family by launch geometry (workgroups x workgroup size), top 40 by total time:")
+    for (n, gx, wx), (c, t) in sorted(gemm.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"  {n:52s} wgs {gx // wx:6d} x {wx:4d}  calls {c:4d}  avg_us {t/c/1e3:9.2f}  total_ms {t/1e6:8.2f}")
+
+
 def from_csv(path):
     """The same three tables from out_kernel_trace.csv (one row per dispatch, timestamps in ns)."""
     agg, attn, gemm = {}, {}, {}
@@ -41,22 +64,17 @@ def from_csv(path):
             e = agg.setdefault(short(n), [0, 0.0])
             e[0] += 1; e[1] += d
             gx, wx = int(r["Grid_Size_X"]), int(r["Workgroup_Size_X"])
-            for tab, key in ((attn, "attn_spatial_kernel"), (gemm, "gemm_kernel")):
-                if key in n:
-                    g = tab.setdefault((short(n) if key == "gemm_kernel" else re.search(r"attn_spatial_kernel<[^>]*>", n).group(0), gx, wx), [0, 0.0])
-                    g[0] += 1; g[1] += d
+            fam = family(n)
+            if fam is not None:
+                g = (attn if fam[0] == "attn" else gemm).setdefault((fam[1], gx, wx), [0, 0.0])
+                g[0] += 1; g[1] += d
     if len(sys.argv) > 2:
         print(sys.argv[2])
     print(f"{'kernel':62s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{k:62s} {c:7d} {t/1e6:10.2f} {t/c/1e3:10.2f} {100*t/total:6.2f}")
     print(f"{'TOTAL':62s} {sum(v[0] for v in agg.values()):7d} {total/1e6:10.2f}")
-    print("\nattn_spatial_kernel by launch geometry (grid_x = threads):")
-    for (n, gx, wx), (c, t) in sorted(attn.items(), key=lambda kv: -kv[1][1]):
-        print(f"  {n:28s} grid_x {gx:9d} wg {wx:4d}  calls {c:4d}  avg_us {t/c/1e3:9.2f}  total_ms {t/1e6:8.2f}")
-    print("\ngemm_kernel by launch geometry (grid_x = threads = workgroups x workgroup size), top 28 by total time:")
-    for (n, gx, wx), (c, t) in sorted(gemm.items(), key=lambda kv: -kv[1][1])[:28]:
-        print(f"  {n:44s} wgs {gx // wx:6d} x {wx:4d}  calls {c:4d}  avg_us {t/c/1e3:9.2f}  total_ms {t/1e6:8.2f}")
+    print_geometry(attn, gemm)
 
 
 def main():
@@ -75,28 +93,20 @@ def main():
     for k, (c, t, p) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"{k:62s} {c:7d} {t/1e3:10.2f} {t/c:10.2f} {p:6.2f}")
     print(f"{'TOTAL':62s} {sum(v[0] for v in agg.values()):7d} {sum(v[1] for v in agg.values())/1e3:10.2f}")
-    # the roofline kernel, split by launch geometry (grid x = workgroups: level 0 of the UNet is the largest grid), so that its
-    # average duration can be compared with bench.py's `roofline.avg_ms` (which times only the level-0 launches)
+    # the attention kernels and the GEMM family split by launch geometry (one line per distinct problem shape class), so that the roofline
+    # kernel's average duration (the level-0 launch) can be read next to bench.py's `roofline.avg_ms`
+    attn, gemm = {}, {}
     try:
-        rows = list(db.execute("select name, grid_x, workgroup_x, count(*), avg(duration), sum(duration) from kernels "
-                               "where name like '%attn_spatial_kernel%' group by name, grid_x, workgroup_x order by sum(duration) desc"))
+        rows = list(db.execute("select name, grid_x, workgroup_x, count(*), sum(duration) from kernels group by name, grid_x, workgroup_x"))
     except sqlite3.Error:
         rows = []
+    for n, gx, wx, c, tot in rows:
+        fam = family(n)
+        if fam is not None:
+            g = (attn if fam[0] == "attn" else gemm).setdefault((fam[1], gx, wx), [0, 0.0])
+            g[0] += c; g[1] += tot
     if rows:
-        print("\nattn_spatial_kernel by launch geometry (grid_x = threads):")
-        for n, gx, wx, c, avg, tot in rows:
-            print(f"  {short(n):28s} grid_x {gx:9d} wg {wx:4d}  calls {c:4d}  avg_us {avg/1e3:9.2f}  total_ms {tot/1e6:8.2f}")
-    # the GEMM family by launch geometry (one line per distinct problem shape class): where the step's GEMM time goes
-    try:
-        rows = list(db.execute("select name, grid_x, workgroup_x, count(*), avg(duration), sum(duration) from kernels "
-                               "where name like '%gemm_kernel%' group by name, grid_x, workgroup_x order by sum(duration) desc limit 28"))
-    except sqlite3.Error:
-        rows = []
-    if rows:
-        print("\ngemm_kernel by launch geometry (grid_x = threads = workgroups x workgroup size), top 28 by total time:")
-        for n, gx, wx, c, avg, tot in rows:
-            print(f"  {short(n):44s} wgs {gx // wx:6d} x {wx:4d}  calls {c:4d}  avg_us {avg/1e3:9.2f}  total_ms {tot/1e6:8.2f}")
-
+        print_geometry(attn, gemm)
 
 if __name__ == "__main__":
     main()

@@ -9,7 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VISTA_HIP_LIB: A/B tooling only (tools/build_rev.sh builds the library of another git revision next to the in-tree one so that two
 # kernel versions can be timed on the SAME box in one call); the product always loads the in-tree build.
-LIB_PATH = os.environ.get("VISTA_HIP_LIB") or os.path.join(_HERE, "lib", "libvista_hip.so")
+# VISTA_ACT_DTYPE (round 6): the 16-bit storage type of activations and weights for THIS process -- "bf16" (default: libvista_hip.so, the dtype
+# BASELINE config 2 names) or "fp16" (libvista_hip_f16.so, the same kernels built with -DVK_F16=1: the reference's own autocast width,
+# sample_utils.py:301-303; 8x closer to the fp32 oracle at the same speed). One storage type per process: ops.ACT follows it.
+ACT_DTYPE = os.environ.get("VISTA_ACT_DTYPE", "bf16").lower()
+if ACT_DTYPE not in ("bf16", "fp16"):
+    raise ValueError(f"VISTA_ACT_DTYPE must be 'bf16' or 'fp16', not {ACT_DTYPE!r}")
+LIB_PATH = os.environ.get("VISTA_HIP_LIB") or os.path.join(_HERE, "lib", "libvista_hip_f16.so" if ACT_DTYPE == "fp16" else "libvista_hip.so")
 
 _vp = C.c_void_p
 _i32 = C.c_int32
@@ -37,10 +43,11 @@ class VkGemmDesc(C.Structure):
         ("mx8_out", _vp), ("mx8_scales", _vp), ("mx8_cols", _i32), ("ld_mx8", _i32), ("ld_mx8s", _i32),
         ("m_begin", _i32), ("m_end", _i32),
         ("gnstat_out", _vp), ("gn_rows", _i32),
+        ("alt_cols_from", _i32),
     ]
 
 
-ABI_VERSION = 6  # vk_abi_version() of the library this table mirrors
+ABI_VERSION = 7  # vk_abi_version() of the library this table mirrors
 
 # name -> argtypes; every entry returns int. Must list every symbol include/vista_hip.h declares
 # (tests/test_abi.py checks the header against this table and against the built library).
@@ -70,6 +77,8 @@ SIGNATURES = {
     "vk_groupnorm_stats_bf16": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "vk_groupnorm_apply_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "vk_groupnorm_finalize_partials": [_vp, _vp, _i32, _i32, _i32, _vp],
+    "vk_groupnorm_fold_max": [],
+    "vk_groupnorm_apply_partials_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp],
     "vk_layernorm_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp],
     "vk_rowstats_bf16": [_vp, _vp, _i32, _i32, _i64, _vp],
     "vk_groupnorm_silu_cat_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp],
@@ -91,6 +100,7 @@ SIGNATURES = {
     "vk_gaussian_sample": [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp],
     "vk_ensemble_variance_sum": [_vp, _vp, _vp, _i32, _i64, _vp],
     "vk_abi_version": [],
+    "vk_act_dtype": [],
 }
 
 _lib = None
@@ -117,6 +127,9 @@ def load():
     if lib.vk_abi_version() != ABI_VERSION:
         raise VistaHipError(f"{LIB_PATH} has ABI version {lib.vk_abi_version()}, this package expects {ABI_VERSION}: rebuild it "
                             "(python -m vista_amd.build --force)")
+    if lib.vk_act_dtype() != (1 if ACT_DTYPE == "fp16" else 0):
+        raise VistaHipError(f"{LIB_PATH} stores {'fp16' if lib.vk_act_dtype() else 'bf16'} but VISTA_ACT_DTYPE={ACT_DTYPE}: "
+                            "the library and the host side must agree on the storage type")
     _lib = lib
     return lib
 

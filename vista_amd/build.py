@@ -24,35 +24,55 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+# the two builds of the same sources: bf16 storage (the default; BASELINE config 2 names bf16) and IEEE fp16 storage (-DVK_F16=1: the reference's
+# autocast width, csrc/common.h). _lib.load() opens the one VISTA_ACT_DTYPE names.
+VARIANTS = {"bf16": ("libvista_hip.so", "", []), "fp16": ("libvista_hip_f16.so", "_f16", ["-DVK_F16=1"])}
+LIB_F16 = os.path.join(LIBDIR, VARIANTS["fp16"][0])
+
+
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(REPO, "include", "vista_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
-        return LIB
+def build(force=False, verbose=True, variants=("bf16", "fp16")):
+    """Compile every HIP source for gfx950 and link the requested variants (default: both). Returns the bf16 library's path."""
     os.makedirs(LIBDIR, exist_ok=True)
-    objs = []
-    procs = []
-    for s in SOURCES:
-        o = os.path.join(LIBDIR, s.replace(".hip", ".o"))
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"),
-               "-I" + CSRC, "-c", os.path.join(CSRC, s), "-o", o] + EXTRA_FLAGS.get(s, [])
+    procs, links = [], []
+    for v in variants:
+        libname, suffix, defs = VARIANTS[v]
+        lib = os.path.join(LIBDIR, libname)
+        if not force and not needs_build(lib):
+            continue
+        objs = []
+        for s in SOURCES:
+            o = os.path.join(LIBDIR, s.replace(".hip", suffix + ".o"))
+            cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(REPO, "include"),
+                   "-I" + CSRC, "-c", os.path.join(CSRC, s), "-o", o] + EXTRA_FLAGS.get(s, []) + defs
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, s + suffix))
+            objs.append(o)
+        links.append((lib, objs))
+    # at most eight compilers at a time (this container has 8 CPUs; gemm.hip alone takes ~2 minutes)
+    running = []
+    for cmd, name in procs:
+        while len(running) >= 8:
+            p, n = running.pop(0)
+            if p.wait() != 0:
+                raise RuntimeError(f"hipcc failed on {n}")
+        running.append((subprocess.Popen(cmd), name))
+    for p, n in running:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {n}")
+    for lib, objs in links:
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((subprocess.Popen(cmd), s))
-        objs.append(o)
-    for p, s in procs:
-        if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        subprocess.check_call(cmd, cwd=LIBDIR)   # (the offload bundler drops per-target intermediates into the cwd: keep them in lib/)
     return LIB
 
 

@@ -270,7 +270,7 @@ __device__ __forceinline__ void attn_spatial_body(char* const smem, const int lo
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8_t kf = *(const bf16x8_t*)(sK + c * 32 * 128 + frag_off[ks]);
 #pragma unroll
-                    for (int b = 0; b < QW; ++b) sacc[b][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][ks], sacc[b][c], 0, 0, 0);
+                    for (int b = 0; b < QW; ++b) sacc[b][c] = vk_mfma(kf, qf[b][ks], sacc[b][c]);
                 }
             }
             if (t == nt - 1 && (S & 63)) {  // mask keys past the end of the sequence (last tile only)
@@ -303,10 +303,10 @@ __device__ __forceinline__ void attn_spatial_body(char* const smem, const int lo
                 for (int J = 0; J < 4; ++J) {
                     const int c = J >> 1, r0 = 8 * (J & 1);
                     uint4 v;
-                    v.x = pack_bf16(sacc[b][c][r0 + 0], sacc[b][c][r0 + 1]);
-                    v.y = pack_bf16(sacc[b][c][r0 + 2], sacc[b][c][r0 + 3]);
-                    v.z = pack_bf16(sacc[b][c][r0 + 4], sacc[b][c][r0 + 5]);
-                    v.w = pack_bf16(sacc[b][c][r0 + 6], sacc[b][c][r0 + 7]);
+                    v.x = pack_bf16x(sacc[b][c][r0 + 0], sacc[b][c][r0 + 1]);
+                    v.y = pack_bf16x(sacc[b][c][r0 + 2], sacc[b][c][r0 + 3]);
+                    v.z = pack_bf16x(sacc[b][c][r0 + 4], sacc[b][c][r0 + 5]);
+                    v.w = pack_bf16x(sacc[b][c][r0 + 6], sacc[b][c][r0 + 7]);
                     psum[b] = dot2_ones(v.x, psum[b]);
                     psum[b] = dot2_ones(v.y, psum[b]);
                     psum[b] = dot2_ones(v.z, psum[b]);
@@ -383,7 +383,7 @@ __device__ __forceinline__ void attn_spatial_body(char* const smem, const int lo
             for (int J = 0; J < 4; ++J) {
                 const bf16x8_t vf = v_frag(sV, d, J);
 #pragma unroll
-                for (int b = 0; b < QW; ++b) oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][J], oacc[b][d], 0, 0, 0);
+                for (int b = 0; b < QW; ++b) oacc[b][d] = vk_mfma_bf16x(vf, pf[b][J], oacc[b][d]);
             }
         }
         __syncthreads();  // retires the DMA of tile t+1 (vmcnt(0)) and frees this stage
@@ -560,9 +560,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) read_k(smem, 0, ks);
-    sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][0], zero16, 0, 0, 0);
+    sc[0] = vk_mfma(kf[0], qf[0][0], zero16);
 #pragma unroll
-    for (int ks = 1; ks < 4; ++ks) sc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[0][ks], sc[0], 0, 0, 0);
+    for (int ks = 1; ks < 4; ++ks) sc[0] = vk_mfma(kf[ks], qf[0][ks], sc[0]);
     __builtin_amdgcn_sched_barrier(0);
 
     // One unit slot. SL = 0..3 = (key block c = SL >> 1, query block b = SL & 1) of tile t; kst / vst = ring stages of tile t (K: t & 1, V: t % 3).
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
         for (int g = 0; g < 8; ++g) {
             if ((g & 1) == 0) {
                 const int ks = g >> 1;
-                nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[nb][ks], ks == 0 ? zero16 : nxt, 0, 0, 0);
+                nxt = vk_mfma(kf[ks], qf[nb][ks], ks == 0 ? zero16 : nxt);
                 if (SL == 2 && g == 0) __syncthreads();   // B_t. vmcnt(0): this wave's pieces of tile t + 1 have landed; lgkmcnt(0): no fragment read is pending
                 // the DMA of tile t + 2 behind B_t, all pieces at once: K(t + 2) over K(t); V(t + 2) over V(t - 1): stage (t + 2) % 3 = (t - 1) % 3.
                 // (One piece per even gap of this unit instead measured -25 %: 6.28 vs 4.71 ms at level 0, profiles/r05_attn_pipe.txt.)
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
                 if (SL == 2) read_k(sK_nxt, 0, ks);
             } else {
                 const int d = (g >> 1) & 1, j = g >> 2, f = 2 * d + j;
-                oacc[pb][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[f], p_frag(pprev + 4 * j), oacc[pb][d], 0, 0, 0);
+                oacc[pb][d] = vk_mfma_bf16x(vf[f], p_frag(pprev + 4 * j), oacc[pb][d]);
                 if (SL == 0) read_v(sV_cur, 0, f);
                 if (SL == 2) read_v(sV_cur, 1, f);
             }
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
                 if (g == 0) { ea = fast_exp2(cur[0]); eb = fast_exp2(cur[1]); }
                 float na = 0.f, nb2 = 0.f;
                 if (g < 7) { na = fast_exp2(cur[2 * g + 2]); nb2 = fast_exp2(cur[2 * g + 3]); }
-                uint32_t w = pack_bf16(ea, eb);
+                uint32_t w = pack_bf16x(ea, eb);
                 asm volatile("" : "+v"(w));   // pinned HERE: the optimiser otherwise sinks the conversions to their use, a whole unit later
                 pcur[g] = w;
                 ps[b][0] += ea;   // (single v_add_f32: the file is built with -fno-slp-vectorize -- packed into v_pk_add_f32 the sixteen adds of
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) oacc[1][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[2 * d + j], p_frag(pw[1] + 4 * j), oacc[1][d], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) oacc[1][d] = vk_mfma_bf16x(vf[2 * d + j], p_frag(pw[1] + 4 * j), oacc[1][d]);
 
     // ---- the one validity test of the zero-base run: finite row sums inside 2^+-100 ----
     float inv[2];
@@ -645,7 +645,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_spatial_pipe_kernel(const uin
         inv[b] = 1.f / l_tot;
     }
     if (__syncthreads_or(bad)) {   // (also a barrier: every wave is done with the LDS ring) -- workgroup-uniform, never taken on real activations
+#ifndef VK_ATTN_NO_FALLBACK   // (-DVK_ATTN_NO_FALLBACK: an A/B build without the inlined general kernel -- the only code of this kernel that uses scratch;
+                              //  timing only, tools/build_variant.sh; profiles/r06_attn_scratch_ab.txt)
         attn_spatial_body<NW, 2, true, true>(smem, logical, q, k, v, o, n_img, heads, S, ldq, ldk, ldo, 1.0f, RESCALE_THR, ldv);
+#endif
         return;
     }
     // Output: lane (l31, lh) holds d = 32 dd + 8 g + 4 lh + e of row l31. Swapping the upper half-wave's quad g with the lower half-wave's quad
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks) sacc = vk_mfma(kf[ks], qf[ks], sacc);
 
         float mx = NEG_BIG;
 #pragma unroll
@@ -756,10 +759,10 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
 #pragma unroll
         for (int J = 0; J < 2; ++J) {
             uint4 v;
-            v.x = pack_bf16(sacc[8 * J + 0], sacc[8 * J + 1]);
-            v.y = pack_bf16(sacc[8 * J + 2], sacc[8 * J + 3]);
-            v.z = pack_bf16(sacc[8 * J + 4], sacc[8 * J + 5]);
-            v.w = pack_bf16(sacc[8 * J + 6], sacc[8 * J + 7]);
+            v.x = pack_bf16x(sacc[8 * J + 0], sacc[8 * J + 1]);
+            v.y = pack_bf16x(sacc[8 * J + 2], sacc[8 * J + 3]);
+            v.z = pack_bf16x(sacc[8 * J + 4], sacc[8 * J + 5]);
+            v.w = pack_bf16x(sacc[8 * J + 6], sacc[8 * J + 7]);
             pf[J] = __builtin_bit_cast(bf16x8_t, v);
         }
 
@@ -788,7 +791,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const uint16_t* __re
                     w[i2] = (uint32_t)lo | ((uint32_t)hi << 16);
                 }
                 const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
-                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, v), pf[J], oacc[d], 0, 0, 0);
+                oacc[d] = vk_mfma_bf16x(__builtin_bit_cast(bf16x8_t, v), pf[J], oacc[d]);
             }
         }
         if (WIDE) {   // (the swaps run in every lane; only the stores are predicated)
@@ -1075,10 +1078,10 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
                 for (int J = 0; J < 4; ++J) {
                     const int c = J >> 1, r0 = 8 * (J & 1);
                     uint4 w;
-                    w.x = pack_bf16(sacc[b][c][r0 + 0], sacc[b][c][r0 + 1]);
-                    w.y = pack_bf16(sacc[b][c][r0 + 2], sacc[b][c][r0 + 3]);
-                    w.z = pack_bf16(sacc[b][c][r0 + 4], sacc[b][c][r0 + 5]);
-                    w.w = pack_bf16(sacc[b][c][r0 + 6], sacc[b][c][r0 + 7]);
+                    w.x = pack_bf16x(sacc[b][c][r0 + 0], sacc[b][c][r0 + 1]);
+                    w.y = pack_bf16x(sacc[b][c][r0 + 2], sacc[b][c][r0 + 3]);
+                    w.z = pack_bf16x(sacc[b][c][r0 + 4], sacc[b][c][r0 + 5]);
+                    w.w = pack_bf16x(sacc[b][c][r0 + 6], sacc[b][c][r0 + 7]);
                     psum[b] = dot2_ones(w.x, psum[b]);
                     psum[b] = dot2_ones(w.y, psum[b]);
                     psum[b] = dot2_ones(w.z, psum[b]);
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
                 bf16x8_t vf;
                 vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3]; vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
 #pragma unroll
-                for (int b = 0; b < QW; ++b) oacc[b][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][J], oacc[b][d], 0, 0, 0);
+                for (int b = 0; b < QW; ++b) oacc[b][d] = vk_mfma_bf16x(vf, pf[b][J], oacc[b][d]);
             }
         }
         __syncthreads();
@@ -1195,6 +1198,9 @@ __global__ __launch_bounds__(NW * 64, QW == 2 ? 2 : 4) void attn_spatial_fp8qk_k
 extern "C" int vk_attn_spatial_fp8qk(const void* q8, const void* k8, const void* q_scales, const void* k_scales, const void* v, void* o, void* o8,
                                      void* o_scales, int32_t n_img, int32_t heads, int32_t S, int32_t ldq8, int32_t ldk8, int32_t ldqs, int32_t ldks,
                                      int32_t ldv, int32_t ldo, int32_t ldo8, int32_t ldos, float scale, void* stream_) {
+#if VK_F16
+    return VK_EINVAL;   // BASELINE config 5 (fp8) exists in the bf16 build only (include/vista_hip.h: vk_act_dtype)
+#endif
     if (!q8 || !k8 || !q_scales || !k_scales || !v || (!o && !o8) || (o8 && !o_scales) || n_img <= 0 || heads <= 0 || S <= 0) return VK_EINVAL;
     if ((S % 8) != 0 || (ldq8 % 16) != 0 || (ldk8 % 16) != 0 || (ldv % 8) != 0 || (o && (ldo % 4) != 0) || (o8 && (ldo8 % 16) != 0)) return VK_EINVAL;
     if ((((size_t)q8) & 15) || (((size_t)k8) & 15) || (o8 && (((size_t)o8) & 15))) return VK_EINVAL;

@@ -12,16 +12,58 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 #define VK_WAVE 64
 
-__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-__device__ __forceinline__ float bf16_to_f32(uint16_t u) { return __builtin_bit_cast(float, ((uint32_t)u) << 16); }
+// ---- the 16-bit STORAGE type of the build ----------------------------------------------------------------------------------------------------
+// Default build (libvista_hip.so): every activation and weight is bf16 (BASELINE config 2 names bf16). -DVK_F16=1 (libvista_hip_f16.so, round 6):
+// the same kernels with IEEE fp16 storage and v_mfma_f32_32x32x16_f16 -- the reference's own autocast width (sample_utils.py:301-303), 3 more
+// mantissa bits at the same MFMA rate and the same instruction counts (v_cvt_pk_f16_f32 / v_cvt_f32_f16 / v_dot2c_f32_f16 exist on gfx950).
+// The helpers below keep their historical "bf16" names: they pack / unpack THE STORAGE TYPE. What stays bf16 in both builds has its own names
+// (*_bf16x): the softmax numerators P and the V operand of the attention P.V product -- the zero-base softmax needs bf16's exponent range
+// (attention.hip), so the q|k|v projections of an fp16 build write their V column block as bf16 (VkGemmDesc.alt_cols_from).
+#ifndef VK_F16
+#define VK_F16 0
+#endif
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
+__device__ __forceinline__ float bf16x_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16x_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 // two fp32 -> packed bf16x2 (round-to-nearest-even; lowers to v_cvt_pk_bf16_f32 on gfx950)
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+__device__ __forceinline__ uint32_t pack_bf16x(float a, float b) {
     f32x2_t v = {a, b};
     bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
     return __builtin_bit_cast(uint32_t, r);
 }
+__device__ __forceinline__ f32x16_t vk_mfma_bf16x(bf16x8_t a, bf16x8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+#if VK_F16
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
+__device__ __forceinline__ float bf16_to_f32(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+// two fp32 -> packed fp16x2 (round-to-nearest-even: v_cvt_pk_f16_f32; values beyond 65504 become inf -- the reference's autocast does the same)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    f32x2_t v = {a, b};
+    f16x2_t r = __builtin_convertvector(v, f16x2_t);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ f32x16_t vk_mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+// sum += x.lo * y.lo + x.hi * y.hi on packed pairs of the storage type (v_dot2c_f32_f16)
+__device__ __forceinline__ float vk_dot2(uint32_t x, uint32_t y, float acc) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, x), __builtin_bit_cast(f16x2_t, y), acc, false);
+}
+#define VK_ONE_PAIR 0x3c003c00u   // (1, 1) in the storage type
+#else
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return bf16x_lo(u); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return bf16x_hi(u); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t u) { return __builtin_bit_cast(float, ((uint32_t)u) << 16); }
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return pack_bf16x(a, b); }
+__device__ __forceinline__ f32x16_t vk_mfma(bf16x8_t a, bf16x8_t b, f32x16_t c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float vk_dot2(uint32_t x, uint32_t y, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, x), __builtin_bit_cast(bf16x2_t, y), acc, false);
+}
+#define VK_ONE_PAIR 0x3f803f80u
+#endif
 __device__ __forceinline__ uint16_t f32_to_bf16(float a) { return (uint16_t)(pack_bf16(a, 0.f) & 0xffffu); }
 
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {

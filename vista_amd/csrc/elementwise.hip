@@ -400,4 +400,5 @@ extern "C" int vk_clip_preprocess_patches(const float* img, void* out, int32_t n
     EW_LAUNCH(clip_preprocess_kernel, (long long)n_img * 3 * out_hw * out_hw, img, (uint16_t*)out, n_img, H, W, out_hw, patch, ldo, sigma_y, sigma_x,
               ks_y, ks_x, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
 }
-extern "C" int vk_abi_version(void) { return 6; }
+extern "C" int vk_abi_version(void) { return 7; }
+extern "C" int vk_act_dtype(void) { return VK_F16 ? 1 : 0; }

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
                         const int i = 5 * g + n;
-                        S[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g & 1][n], xf[i >> 1], S[i & 1], 0, 0, 0);
+                        S[i & 1] = vk_mfma(fr[g & 1][n], xf[i >> 1], S[i & 1]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(FF_NT, 2) void ff_fused_kernel(const VkGemmDesc p1,
 #pragma unroll
                     for (int n = 0; n < 5; ++n) {
                         const int i = 5 * v2 + n;
-                        if (!(DBG & 4)) O[i % 10][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[v2 & 1][n], hf[i / 10], O[i % 10][0], 0, 0, 0);
+                        if (!(DBG & 4)) O[i % 10][0] = vk_mfma(fr[v2 & 1][n], hf[i / 10], O[i % 10][0]);
                         else asm volatile("" :: "v"(fr[v2 & 1][n]), "v"(hf[i / 10]));
                         // One DMA piece after each of the first 15 MFMAs. Measured alternatives: all 15 pieces first, then the MFMAs (1.43 ms per
                         // launch against 1.42: the late MFMAs stretch the partner's gelu phase -- MFMA and VALU issue of the two waves of a SIMD

@@ -287,7 +287,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 16) ? 4 : 2) void gemm_ke
         for (int fi = 0; fi < FX; ++fi)
 #pragma unroll
             for (int fj = 0; fj < FY; ++fj)
-                acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+                acc[fi][fj] = vk_mfma(xf[fi], yf[fj], acc[fi][fj]);
     };
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE_BYTES;
@@ -499,7 +499,7 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     // tiles x slices ~ one full round of CUs; fp32 partials go to the caller's workspace and a finishing pass applies the epilogue.
     // Not combined with the LayerNorm fold / row-sum emission (their epilogues need the finished accumulator in registers).
     int ksplit = 1;
-    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && cfg != 5 && !d->ln_stats && !d->rowstat_out && !d->act &&
+    if (epi == EPI_LINEAR && force == 0 && d->splitk_ws && cfg != 4 && cfg != 3 && cfg != 5 && !d->ln_stats && !d->rowstat_out && !d->act && !d->alt_cols_from &&
         d->m_begin == 0 && d->m_end == d->M) {   // (the finishing pass walks all M rows: no split-K on a row range)
         const bool ok320s = (amode != AMODE_CONV3D) && (d->N % 320 == 0);
         const int bn = ok320s ? 320 : 256;
@@ -619,6 +619,10 @@ inline int validate(const VkGemmDesc* d) {
                        (((size_t)d->mx8_out) & 15) != 0 || d->rowstat_out || (d->ldc % 8) != 0 || (((size_t)d->out) & 15) != 0 ||
                        (d->amode != AMODE_DENSE) || d->res1 || d->res2 || d->rowvec || d->rowvec2 ||
                        (unsigned long long)d->M * 2ull * (unsigned)d->ldc >= 0xfffff000ull))  // (what epi_plan needs to take the LDS-staged epilogue)
+        return VK_EINVAL;
+    // (ABI v7, read by the fp16 build only -- validated in both) columns from alt_cols_from on leave as bf16: LINEAR, 16-bit out, whole fragments, no statistics of the output
+    if (d->alt_cols_from != 0 && (d->alt_cols_from < 0 || (d->alt_cols_from % 32) != 0 || d->alt_cols_from >= d->N || d->epi != EPI_LINEAR || d->out_f32 ||
+                                  d->rowstat_out || d->gnstat_out || d->mx8_out))
         return VK_EINVAL;
     return VK_OK;
 }

@@ -32,7 +32,7 @@ __device__ __forceinline__ uint4 widen_pair(uint2 qa, uint2 qb) {
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
 
-// 16-byte output store of the LDS-staged epilogues. -DVK_EPI_NT_STORES=1 builds them with the non-temporal hint (an A/B build: tools/build_nt_variant.sh;
+// 16-byte output store of the LDS-staged epilogues. -DVK_EPI_NT_STORES=1 builds them with the non-temporal hint (an A/B build: tools/build_variant.sh;
 // the GroupNorm apply pass gained 20 % from it on tensors that do not fit the Infinity Cache, profiles/r05_gn_nontemporal_ab.txt).
 #ifndef VK_EPI_NT_STORES
 #define VK_EPI_NT_STORES 0
@@ -85,6 +85,15 @@ __device__ __forceinline__ uint4 mx_quant_block(const float (&v)[4][4], int& e8m
     const auto r13 = __builtin_amdgcn_permlane32_swap(q[1], q[3], false, false);
     e8m0 = ex + 127;
     return make_uint4(r02[0], r02[1], r13[0], r13[1]);
+}
+
+// Output pack of the LINEAR epilogues: the build's storage type, except -- fp16 build only -- the columns from VkGemmDesc.alt_cols_from on, which
+// leave as bf16 (the V block of a fused q|k|v projection: common.h). `n` = any column of the 32-column fragment being packed (alt_cols_from % 32 == 0).
+__device__ __forceinline__ uint32_t pack_out(float a, float b, const VkGemmDesc& p, int n) {
+#if VK_F16
+    if (p.alt_cols_from > 0 && n >= p.alt_cols_from) return pack_bf16x(a, b);
+#endif
+    return pack_bf16(a, b);
 }
 
 // LayerNorm fold (VkGemmDesc.ln_*): (mean, rstd) of activation row m from the producer's partial sums, summed in slab order. The GEMM
@@ -211,8 +220,8 @@ __device__ __forceinline__ void gemm_epilogue(const VkGemmDesc& p, f32x16_t (&ac
                     if (OUT_F32) {
                         *(float4*)((float*)p.out + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                     } else {
-                        packed[g].x = pack_bf16(v[0], v[1]);
-                        packed[g].y = pack_bf16(v[2], v[3]);
+                        packed[g].x = pack_out(v[0], v[1], p, n);
+                        packed[g].y = pack_out(v[2], v[3], p, n);
                         if (p.rowstat_out) {
                             const float a0 = bf16_lo(packed[g].x), a1 = bf16_hi(packed[g].x), a2 = bf16_lo(packed[g].y), a3 = bf16_hi(packed[g].y);
                             ssum += (a0 + a1) + (a2 + a3);
@@ -465,23 +474,21 @@ __device__ __forceinline__ void gn_reduce_store(float (&gs)[NG], float (&gq)[NG]
 // the two pairs (columns c .. c+3, c = 32 fi + 8 g + 4 lh of the wave tile) of one packed quad into the group accumulators
 template <int CPG, int NG>
 __device__ __forceinline__ void gn_accumulate_quad(float (&gs)[NG], float (&gq)[NG], const int fi, const int g, const uint2 packed, const uint32_t lo_mask) {
-    typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
-    const bf2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+    constexpr uint32_t one = VK_ONE_PAIR;   // (1, 1) in the build's storage type; vk_dot2 = v_dot2c_f32_bf16 / v_dot2c_f32_f16 (common.h)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const uint32_t w = h ? packed.y : packed.x;
         const int c0 = 32 * fi + 8 * g + 2 * h;                 // the pair's first column in a lane of the lower half-wave; + 4 in the upper one
         const int G0 = c0 / CPG, G1 = (c0 + 4) / CPG;
         if (G0 == G1) {
-            const bf2_t v = __builtin_bit_cast(bf2_t, w);
-            gs[G0] = __builtin_amdgcn_fdot2_f32_bf16(v, one, gs[G0], false);
-            gq[G0] = __builtin_amdgcn_fdot2_f32_bf16(v, v, gq[G0], false);
+            gs[G0] = vk_dot2(w, one, gs[G0]);
+            gq[G0] = vk_dot2(w, w, gq[G0]);
         } else {   // the half-waves' pairs belong to different groups: each lane adds its pair to its own group and zeros to the other
-            const bf2_t v0 = __builtin_bit_cast(bf2_t, w & lo_mask), v1 = __builtin_bit_cast(bf2_t, w & ~lo_mask);
-            gs[G0] = __builtin_amdgcn_fdot2_f32_bf16(v0, one, gs[G0], false);
-            gq[G0] = __builtin_amdgcn_fdot2_f32_bf16(v0, v0, gq[G0], false);
-            gs[G1] = __builtin_amdgcn_fdot2_f32_bf16(v1, one, gs[G1], false);
-            gq[G1] = __builtin_amdgcn_fdot2_f32_bf16(v1, v1, gq[G1], false);
+            const uint32_t v0 = w & lo_mask, v1 = w & ~lo_mask;
+            gs[G0] = vk_dot2(v0, one, gs[G0]);
+            gq[G0] = vk_dot2(v0, v0, gq[G0]);
+            gs[G1] = vk_dot2(v1, one, gs[G1]);
+            gq[G1] = vk_dot2(v1, v1, gq[G1]);
         }
     }
 }
@@ -585,8 +592,8 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
                     const float t0 = bf16_lo(r.x) + b2.x, t1 = bf16_hi(r.x) + b2.y, t2 = bf16_lo(r.y) + b2.z, t3 = bf16_hi(r.y) + b2.w;
                     v[0] += p.beta * t0; v[1] += p.beta * t1; v[2] += p.beta * t2; v[3] += p.beta * t3;
                 }
-                packed[g].x = pack_bf16(v[0], v[1]);
-                packed[g].y = pack_bf16(v[2], v[3]);
+                packed[g].x = pack_out(v[0], v[1], p, n0 + wn * NW + fi * 32);
+                packed[g].y = pack_out(v[2], v[3], p, n0 + wn * NW + fi * 32);
                 if (GNC == 0 && p.rowstat_out) {
                     const float a0 = bf16_lo(packed[g].x), a1 = bf16_hi(packed[g].x), a2 = bf16_lo(packed[g].y), a3 = bf16_hi(packed[g].y);
                     ssum += (a0 + a1) + (a2 + a3);

@@ -463,11 +463,17 @@ int gemm_fp8_entry(const VkGemmDesc* d, const F8Args& q, hipStream_t stream) {
 }  // namespace
 
 extern "C" int vk_gemm_fp8(const VkGemmDesc* d, const float* a_scale, const float* w_scale, int32_t k_real, void* stream_) {
+#if VK_F16
+    return VK_EINVAL;   // BASELINE config 5 (fp8) exists in the bf16 build only (include/vista_hip.h: vk_act_dtype)
+#endif
     const F8Args q{a_scale, 0, w_scale, k_real, nullptr, 0, nullptr, 0};
     return gemm_fp8_entry(d, q, (hipStream_t)stream_);
 }
 
 extern "C" int vk_gemm_fp8_mx(const VkGemmDesc* d, const VkFp8Args* a, void* stream_) {
+#if VK_F16
+    return VK_EINVAL;   // BASELINE config 5 (fp8) exists in the bf16 build only (include/vista_hip.h: vk_act_dtype)
+#endif
     if (!a) return VK_EINVAL;
     const F8Args q{a->a_scale, a->a_scale_rows, a->w_scale, a->k_real, (const uint8_t*)a->a_mx, a->ld_mx, (uint8_t*)a->mx_out, a->ld_mx_out};
     return gemm_fp8_entry(d, q, (hipStream_t)stream_);

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
 #pragma unroll
         for (int fi = 0; fi < PFX; ++fi)
 #pragma unroll
-            for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+            for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = vk_mfma(xf[fi], yf[fj], acc[fi][fj]);
     };
     // the ten MFMAs of one k-substep with the nine pieces of the next K-step, one after each of the first nine MFMAs
     auto mma_dma = [&](const bf16x8_t* xf, const bf16x8_t* yf, const int stage) __attribute__((always_inline)) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         for (int fi = 0; fi < PFX; ++fi)
 #pragma unroll
             for (int fj = 0; fj < PFY; ++fj) {
-                acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[fi], yf[fj], acc[fi][fj], 0, 0, 0);
+                acc[fi][fj] = vk_mfma(xf[fi], yf[fj], acc[fi][fj]);
                 if (fi * 2 + fj < PWP + PAP) {
                     PIPE_SB();
                     dma_q(fi * 2 + fj, stage);

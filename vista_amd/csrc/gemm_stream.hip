@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gemm_stream_kernel(cons
 #pragma unroll
         for (int ks = 0; ks < 20; ++ks) {
             const bf16x8_t xf = *(const bf16x8_t*)(at + (ks >> 2) * 128 + frag_off[ks & 3]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf, acc, 0, 0, 0);
+            acc = vk_mfma(wf[ks], xf, acc);
         }
         GS_T(2)
         // ---- epilogue: lane (l31, lh) owns row m0 + l31, columns nb + 8 g + 4 lh + e ----
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void gemm_stream_kernel(cons
 // Does the weight-stationary streaming kernel take this problem? (host arithmetic; vk_gemm_bf16 / vk_gemm_rowstat_parts / vk_gemm_tile_choice ask)
 // Returns 0 = no, 10 = yes (ten-wave workgroups, 320 output columns each; N = 320, 640 or 960).
 extern "C" int vk_gemm_stream_fit(const VkGemmDesc* d) {
-    if (!d || d->amode != 0 || d->epi != 0 || d->out_f32 || d->K != GS_K || d->A2 || d->act || d->mx8_out || d->res2 || d->rowvec2) return 0;
+    if (!d || d->amode != 0 || d->epi != 0 || d->out_f32 || d->K != GS_K || d->A2 || d->act || d->mx8_out || d->res2 || d->rowvec2 || d->alt_cols_from) return 0;
     if ((d->tile_cfg & 7) != 0 && (d->tile_cfg & 7) != 6) return 0;                 // a forced tiled variant
     // auto: only when every CU gets >= 8 row tiles, and only the form that measured faster than the tiled kernels at the BASELINE shape
     // (profiles/r04_gemm_stream.txt): N = 320 with a residual and neither row-sum emission, row vector nor folded LayerNorm (proj_out: 0.194 vs

@@ -163,18 +163,38 @@ __device__ __forceinline__ void gn_st16(uint16_t* p, const uint4 v) {
     }
 }
 
-template <bool NTL, bool NTS>
+// FOLD (round 6): `stats` holds the image groups' STAGE-1 slots ([group][nparts][64]) instead of their finished sums, and every workgroup sums its own
+// group's slots first -- the arithmetic of gn_finalize_kernel (four strided lanes per value, then the fixed (0 + 1) + (2 + 3) combine), so the
+// result is bitwise that of the finalize launch it replaces. nparts <= GN_FOLD_MAX slots = at most 64 KiB read from L2 per workgroup; the finalize
+// launch it removes was 7.9 us of launch overhead per norm (105 norms per step, profiles/r05_step_kernels.txt).
+constexpr int GN_FOLD_MAX = 256;
+template <bool NTL, bool NTS, bool FOLD>
 __global__ void gn_apply_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ x2, int C1, uint16_t* __restrict__ y, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const float* __restrict__ stats, int S, int C, int CG, int R,
-                                int frames_per_group, float inv_cnt, float eps, int do_silu, int tok_per_wg) {
+                                int frames_per_group, float inv_cnt, float eps, int do_silu, int tok_per_wg, int nparts) {
+    __shared__ float fold_red[FOLD ? 4 : 1][64];
+    __shared__ float fold_tot[64];
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
     const int tok0 = blockIdx.x * tok_per_wg;
     const int tok1 = min(tok0 + tok_per_wg, S);
     const int chunk = tid % CG, r = tid / CG;
+    const float* st = stats + (size_t)(img / frames_per_group) * 64;  // [32 sums | 32 sums of squares]
+    if constexpr (FOLD) {
+        const float* src = stats + (size_t)(img / frames_per_group) * nparts * 64;
+        for (int idx = tid; idx < 256; idx += blockDim.x) {   // (workgroups of 192 .. 320 threads: the 4 x 64 (lane, value) pairs of the finalize kernel)
+            const int v = idx & 63, j = idx >> 6;
+            float a = 0.f;
+            for (int i = j; i < nparts; i += 4) a += src[(size_t)i * 64 + v];
+            fold_red[j][v] = a;
+        }
+        __syncthreads();
+        if (tid < 64) fold_tot[tid] = (fold_red[0][tid] + fold_red[1][tid]) + (fold_red[2][tid] + fold_red[3][tid]);
+        __syncthreads();
+        st = fold_tot;
+    }
     if (r >= R) return;
     const int cpg = C >> 5;
-    const float* st = stats + (size_t)(img / frames_per_group) * 64;  // [32 sums | 32 sums of squares]
     float a[8], b[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -504,7 +524,7 @@ int gn_finalize(float* partial_ws, float* sums, int ngroups, int nparts, hipStre
 }
 
 int gn_stats(const void* x, const void* x2, int C1, float* sums, float* partial_ws, int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group,
-             void* stream_, float* amax_part = nullptr) {
+             void* stream_, float* amax_part = nullptr, bool finalize = true) {
     hipStream_t stream = (hipStream_t)stream_;
     GnGeom g;
     if (!x || !sums || !partial_ws || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
@@ -517,11 +537,23 @@ int gn_stats(const void* x, const void* x2, int C1, float* sums, float* partial_
         hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(g.threads), lds_bytes, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, partial_ws, S, C,
                            g.CG, g.R, g.tok, (float*)nullptr);
     VK_CHECK_LAUNCH();
+    if (!finalize) return VK_OK;   // (the apply pass folds the slots itself: gn_fold_parts)
     return gn_finalize(partial_ws, sums, g.ngroups, frames_per_group * g.nchunks, stream);
 }
 
+// Slots per image group of the statistics pass when the apply pass may fold them itself (0 = keep the finalize launch): at most GN_FOLD_MAX,
+// VISTA_GN_FOLD=0 restores the three-launch GroupNorm everywhere (A/B hook; bitwise the same output either way).
+int gn_fold_parts(int32_t n_img, int32_t S, int32_t C, int32_t frames_per_group) {
+    static const bool on = [] { const char* e = getenv("VISTA_GN_FOLD"); return !e || atoi(e) != 0; }();
+    GnGeom g;
+    if (!on || !gn_geom(n_img, S, C, frames_per_group, g)) return 0;
+    const long long np = (long long)frames_per_group * g.nchunks;
+    return np <= GN_FOLD_MAX ? (int)np : 0;
+}
+
+// fold_nparts > 0: `sums` are the groups' stage-1 slots ([group][fold_nparts][64]) and the apply workgroups fold them themselves (no finalize launch)
 int gn_apply(const void* x, const void* x2, int C1, void* y, const float* gamma, const float* beta, const float* sums, int32_t n_img, int32_t S,
-             int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream_) {
+             int32_t C, int32_t frames_per_group, float count, float eps, int32_t silu, void* stream_, int fold_nparts = 0) {
     hipStream_t stream = (hipStream_t)stream_;
     GnGeom g;
     if (!x || !y || !gamma || !beta || !sums || count <= 0.f || !gn_geom(n_img, S, C, frames_per_group, g)) return VK_EINVAL;
@@ -535,12 +567,20 @@ int gn_apply(const void* x, const void* x2, int C1, void* y, const float* gamma,
     // VISTA_GN_NT = 0..3 forces (bit 0 = loads, bit 1 = stores) for an A/B; unset = the size rule.
     static const int nt_env = [] { const char* e = getenv("VISTA_GN_NT"); return e ? atoi(e) & 3 : -1; }();
     const int nt_mode = nt_env >= 0 ? nt_env : ((long long)n_img * S * C * 2 >= (96LL << 20) ? 3 : 0);
-#define VK_GN_APPLY(NL, NS) hipLaunchKernelGGL((gn_apply_kernel<NL, NS>), grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, (uint16_t*)y, \
-                                               gamma, beta, sums, S, C, g.CG, g.R, frames_per_group, 1.f / count, eps, silu, tok_per_wg)
-    if (nt_mode == 3) VK_GN_APPLY(true, true);
-    else if (nt_mode == 2) VK_GN_APPLY(false, true);
-    else if (nt_mode == 1) VK_GN_APPLY(true, false);
-    else VK_GN_APPLY(false, false);
+    if (fold_nparts < 0 || fold_nparts > GN_FOLD_MAX) return VK_EINVAL;
+#define VK_GN_APPLY(NL, NS, FO) hipLaunchKernelGGL((gn_apply_kernel<NL, NS, FO>), grid, dim3(g.threads), 0, stream, (const uint16_t*)x, (const uint16_t*)x2, C1, (uint16_t*)y, \
+                                                   gamma, beta, sums, S, C, g.CG, g.R, frames_per_group, 1.f / count, eps, silu, tok_per_wg, fold_nparts)
+    if (fold_nparts > 0) {
+        if (nt_mode == 3) VK_GN_APPLY(true, true, true);
+        else if (nt_mode == 2) VK_GN_APPLY(false, true, true);
+        else if (nt_mode == 1) VK_GN_APPLY(true, false, true);
+        else VK_GN_APPLY(false, false, true);
+    } else {
+        if (nt_mode == 3) VK_GN_APPLY(true, true, false);
+        else if (nt_mode == 2) VK_GN_APPLY(false, true, false);
+        else if (nt_mode == 1) VK_GN_APPLY(true, false, false);
+        else VK_GN_APPLY(false, false, false);
+    }
 #undef VK_GN_APPLY
     VK_CHECK_LAUNCH();
     return VK_OK;
@@ -557,6 +597,21 @@ extern "C" int vk_groupnorm_apply_bf16(const void* x, void* y, const float* gamm
     return gn_apply(x, nullptr, 0, y, gamma, beta, sums, n_img, S, C, frames_per_group, count, eps, silu, stream_);
 }
 
+// ABI v7: the apply pass on STAGE-1 slots (a GEMM epilogue's VkGemmDesc.gnstat_out, one slot per 64 output rows: nchunks = S / 64 per image), folding
+// them itself -- two launches per GroupNorm (producer, apply) instead of three. Needs frames_per_group * nchunks <= vk_groupnorm_fold_max() (else
+// VK_EINVAL: run vk_groupnorm_finalize_partials + vk_groupnorm_apply_bf16). Bitwise the output of that pair.
+extern "C" int vk_groupnorm_fold_max(void) {
+    static const bool on = [] { const char* e = getenv("VISTA_GN_FOLD"); return !e || atoi(e) != 0; }();
+    return on ? GN_FOLD_MAX : 0;
+}
+
+extern "C" int vk_groupnorm_apply_partials_bf16(const void* x, void* y, const float* gamma, const float* beta, const float* partial, int32_t n_img,
+                                                int32_t S, int32_t C, int32_t nchunks, int32_t frames_per_group, float count, float eps, int32_t silu,
+                                                void* stream_) {
+    if (!partial || nchunks <= 0 || frames_per_group <= 0 || (long long)frames_per_group * nchunks > GN_FOLD_MAX) return VK_EINVAL;
+    return gn_apply(x, nullptr, 0, y, gamma, beta, partial, n_img, S, C, frames_per_group, count, eps, silu, stream_, frames_per_group * nchunks);
+}
+
 // ABI v6: stage 2 alone, on the stage-1 slots a GEMM epilogue wrote (VkGemmDesc.gnstat_out: one slot per 64 output rows)
 extern "C" int vk_groupnorm_finalize_partials(float* partial, float* sums, int32_t n_img, int32_t nchunks, int32_t frames_per_group, void* stream_) {
     if (!partial || !sums || n_img <= 0 || nchunks <= 0 || frames_per_group <= 0 || (n_img % frames_per_group) != 0) return VK_EINVAL;
@@ -570,10 +625,11 @@ extern "C" int vk_groupnorm_silu_cat_bf16(const void* x1, const void* x2, void* 
     if (!x1 || !x2 || !stats_ws || frames_per_group <= 0 || n_img <= 0 || C1 <= 0 || C2 <= 0 || (C1 % 8) != 0 || (C2 % 8) != 0) return VK_EINVAL;
     const int C = C1 + C2;
     float* partial = stats_ws + (size_t)(n_img / frames_per_group) * 64;
-    int rc = gn_stats(x1, x2, C1, stats_ws, partial, n_img, S, C, frames_per_group, stream_);
+    const int fold = gn_fold_parts(n_img, S, C, frames_per_group);
+    int rc = gn_stats(x1, x2, C1, stats_ws, partial, n_img, S, C, frames_per_group, stream_, nullptr, fold == 0);
     if (rc != VK_OK) return rc;
     const float count = (float)(C / 32) * (float)S * (float)frames_per_group;
-    return gn_apply(x1, x2, C1, y, gamma, beta, stats_ws, n_img, S, C, frames_per_group, count, eps, silu, stream_);
+    return gn_apply(x1, x2, C1, y, gamma, beta, fold ? partial : stats_ws, n_img, S, C, frames_per_group, count, eps, silu, stream_, fold);
 }
 
 extern "C" int vk_groupnorm_silu_fp8(const void* x1, const void* x2, void* y8, float* scale_out, const float* gamma, const float* beta,
@@ -614,10 +670,11 @@ extern "C" int vk_groupnorm_silu_bf16(const void* x, void* y, const float* gamma
     if (!stats_ws || frames_per_group <= 0 || n_img <= 0) return VK_EINVAL;
     // workspace: [n_img/fpg][64] sums, then [n_img][chunks][64] partial sums
     float* partial = stats_ws + (size_t)(n_img / frames_per_group) * 64;
-    int rc = vk_groupnorm_stats_bf16(x, stats_ws, partial, n_img, S, C, frames_per_group, stream_);
+    const int fold = gn_fold_parts(n_img, S, C, frames_per_group);
+    int rc = gn_stats(x, nullptr, 0, stats_ws, partial, n_img, S, C, frames_per_group, stream_, nullptr, fold == 0);
     if (rc != VK_OK) return rc;
     const float count = (float)(C / 32) * (float)S * (float)frames_per_group;
-    return vk_groupnorm_apply_bf16(x, y, gamma, beta, stats_ws, n_img, S, C, frames_per_group, count, eps, silu, stream_);
+    return gn_apply(x, nullptr, 0, y, gamma, beta, fold ? partial : stats_ws, n_img, S, C, frames_per_group, count, eps, silu, stream_, fold);
 }
 
 extern "C" int vk_layernorm_bf16(const void* x, void* y, void* sum_out, const float* gamma, const float* beta, const float* addvec,

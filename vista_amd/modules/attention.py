@@ -166,7 +166,7 @@ class FeedForward(nn.Module, Packable):
         """BASELINE config 5 for THIS FeedForward? Not where the fused bf16 kernel runs (level 0, width 320): round-4 same-box probe
         (tools/fp8_vs_bf16_probe.py, 460800 tokens): fused bf16 1.28 ms at 2.7e-3 of fp32 against 1.38 ms at 4.0e-2 for the fp8 pair --
         fp8 there costs time AND accuracy; levels 1 / 2: 0.93 vs 1.17 ms and 0.70 vs 1.03 ms, fp8 stays."""
-        if not FP8["feedforward"]:
+        if not FP8["feedforward"] or ops.ACT is not torch.bfloat16:   # (config 5 exists in the bf16 build only)
             return False
         w2 = self.net[2].weight
         return not (FF_FUSED and w2.shape[0] == ops.FF_FUSED_WIDTH and w2.shape[1] % 64 == 0 and 128 <= w2.shape[1] <= ops.FF_FUSED_MAX_HIDDEN)
@@ -336,6 +336,8 @@ class BasicTransformerBlock(nn.Module, Packable):
         C = self.dim
         scale = self.attn1.dim_head ** -0.5
         att8 = None
+        if ops.ACT is not torch.bfloat16 and (QKV_SPLIT or FP8["attention"]):
+            raise ops._lib.VistaHipError("VISTA_ACT_DTYPE=fp16: the q|k + V^T split and the fp8 score product (BASELINE config 5) exist in the bf16 build only")
         if QKV_SPLIT:
             qk = ops.linear(x, pk["qk"], ln=stats)
             vt = ops.linear_vt(x, pk["v"], S, ln=stats)
@@ -355,7 +357,7 @@ class BasicTransformerBlock(nn.Module, Packable):
         else:
             # ONE q|k|v GEMM (attention.py:344-346), LayerNorm(norm1) folded: x is read once and never as a normalised copy; the attention
             # kernel takes V as the third column block and transposes its tiles on the way out of LDS (no V^T tensor, no TRANS GEMM)
-            qkv = ops.linear(x, pk["qkv"], ln=stats)
+            qkv = ops.linear(x, pk["qkv"], ln=stats, alt_cols_from=2 * C)   # (fp16 build: the V block leaves as bf16; no-op in the bf16 build)
             att = ops.attn_spatial(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], n_img, self.n_heads, S, scale, v_rows=True, q_log2=Q_LOG2)
         cv = self.attn2.context_vector(context)  # attn2(norm2(x), context): constant over the image's tokens
         if att8 is not None:

@@ -77,7 +77,7 @@ class VideoTransformerBlock(nn.Module, Packable):
         pk = self.packed()
         a1 = self.attn1.packed()
         x, st = self.ff_in.forward_folded(x_mix, stats, pk["ffin_in"], self.norm_in, res1=x_mix, emit_stats=True)
-        qkv = ops.linear(x, pk["qkv"], ln=st)
+        qkv = ops.linear(x, pk["qkv"], ln=st, alt_cols_from=2 * x.shape[-1])   # (fp16 build: the V block leaves as bf16; no-op in the bf16 build)
         att = ops.attn_temporal(qkv, B, T, S, self.n_heads, self.attn1.dim_head ** -0.5)
         if self.has_cross:
             cv = self.attn2.context_vector(clip_context)  # (b, dim) f32, constant over the clip's frames and pixels

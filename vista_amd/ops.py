@@ -15,7 +15,10 @@ from ._lib import VkFp8Args, VkGemmDesc, check
 
 AMODE_DENSE, AMODE_CONV3X3, AMODE_TEMPORAL3, AMODE_CONV3D = 0, 1, 2, 3
 EPI_LINEAR, EPI_GEGLU, EPI_TRANS = 0, 1, 2
-BF16 = torch.bfloat16
+# The 16-bit storage type of activations and packed weights: bf16 unless the process runs the fp16 build (VISTA_ACT_DTYPE=fp16, _lib.ACT_DTYPE).
+# `BF16` is the historical name used throughout this file for "the storage type"; ACT is the same object under an honest name.
+ACT = torch.float16 if _lib.ACT_DTYPE == "fp16" else torch.bfloat16
+BF16 = ACT
 F32 = torch.float32
 
 
@@ -347,7 +350,7 @@ def _fill_epilogue(d, pw, out, M, rowvec, rows_per_vec, res1, res2, alpha, beta,
 
 
 def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=None, res2=None, alpha=1.0, beta=0.0, rowvec2=None,
-           x2=None, ln=None, emit_stats=False, act=None, mx8_cols=0):
+           x2=None, ln=None, emit_stats=False, act=None, mx8_cols=0, alt_cols_from=0):
     """out = alpha*(act(X @ W^T + bias + rowvec[row // rows_per_vec]) + res1) + beta*(res2 + rowvec2[row // rows_per_vec]); act: None | "gelu".
     x: (..., K) bf16. x2: second source of a channel concat, X = [x | x2] (never materialised). ln: RowStats of x's rows when pw has
     a LayerNorm folded in (X = LayerNorm(x)). emit_stats: also return the RowStats of the (bf16) output -> (out, stats)."""
@@ -390,6 +393,9 @@ def linear(x, pw, *, out=None, out_f32=False, rowvec=None, rows_per_vec=0, res1=
         if act != "gelu" or pw.geglu:
             raise ValueError("linear: act must be None or 'gelu' (exact-erf GELU in the LINEAR epilogue)")
         d.act = 1
+    # fp16 build: output columns from alt_cols_from on leave as bf16 (the V block of a fused q|k|v projection: the attention kernels keep P.V in
+    # bf16 in both builds, include/vista_hip.h). Ignored by the bf16 build, where every column is bf16 anyway.
+    d.alt_cols_from = int(alt_cols_from)
     stats = _gemm(d, emit_stats, x.device)
     if mx is not None:
         return out, mx[0], mx[1]
@@ -788,6 +794,9 @@ def attn_spatial(q, k, vt, n_img, heads, S, scale=None, v_rows=False, q_log2=Fal
             check(lib.vk_attn_spatial_qkv_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), vt.stride(0), o.stride(0), sc,
                                                _stream()), "vk_attn_spatial_qkv_bf16")
     else:
+        if ACT is not torch.bfloat16:
+            raise _lib.VistaHipError("attn_spatial with a V^T tensor: bf16 build only (in the fp16 build V must come from a q|k|v projection launched "
+                                     "with alt_cols_from, i.e. as bf16 rows)")
         check(lib.vk_attn_spatial_bf16(_p(q), _p(k), _p(vt), _p(o), n_img, heads, S, q.stride(0), k.stride(0), o.stride(0), sc, _stream()),
               "vk_attn_spatial_bf16")
     if ev is not None:
@@ -919,10 +928,15 @@ def groupnorm(x, gamma, beta, eps, silu, frames_per_group=1, out=None, gn=None):
         out = torch.empty_like(x)
     if _gn_partials_ok(gn, n_img, S, Cc):
         lib = _lib.load()
+        count = float(Cc // 32) * float(S) * float(frames_per_group)
+        if frames_per_group * gn.nchunks <= lib.vk_groupnorm_fold_max():   # ABI v7: the apply workgroups fold the slots themselves (no finalize launch)
+            check(lib.vk_groupnorm_apply_partials_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(gn.t), n_img, S, Cc, gn.nchunks, frames_per_group, count,
+                                                       float(eps), 1 if silu else 0, _stream()), "vk_groupnorm_apply_partials_bf16")
+            gn.t = None   # consumed
+            return out
         sums = torch.empty((n_img // frames_per_group) * 64, dtype=F32, device=x.device)
         check(lib.vk_groupnorm_finalize_partials(_p(gn.t), _p(sums), n_img, gn.nchunks, frames_per_group, _stream()), "vk_groupnorm_finalize_partials")
         gn.t = None   # consumed
-        count = float(Cc // 32) * float(S) * float(frames_per_group)
         check(lib.vk_groupnorm_apply_bf16(_p(x), _p(out), _p(gamma), _p(beta), _p(sums), n_img, S, Cc, frames_per_group, count, float(eps),
                                           1 if silu else 0, _stream()), "vk_groupnorm_apply_bf16")
         return out
