@@ -245,7 +245,7 @@ def hbm_rooflines(ops, n_img, H, W):
     nbytes = float(x.numel() * 2)
     cases = [
         ("GroupNorm(32)+SiLU level 0 (50 x 9216 x 320): gn_stats + gn_apply (the apply pass folds the statistics slots itself since round 6)",
-         lambda: ops.groupnorm(x, gam, bet, 1e-5, True), 10.0 * x.numel(), 3.0 * nbytes, "hbm"),   # statistics read + apply read + apply write
+         lambda: ops.groupnorm(x, gam, bet, 1e-5, True), 10.0 * x.numel(), 2.0 * nbytes, "hbm"),   # (the two-pass form reads x twice: its traffic is up to 3 x nbytes)
         ("attn_temporal_kernel level 0: 92160 (pixel, head) problems of 25 x 25 x 64 (video_attention.py:116-127)",
          lambda: ops.attn_temporal(qkv, B, T, S, heads), 4.0 * B * S * heads * T * T * 64, 4.0 * nbytes, "hbm"),   # q | k | v read + o written
     ]

@@ -2,9 +2,10 @@
 goldens as the bf16 build. The storage type is fixed per process, so the checks run in a worker process (tests/_f16_worker.py) and this file
 states the bounds.
 
-Stated tolerance of the fp16 build (profiles/r06_error_budget.txt predicts 1.5e-3 for the full-width network; the reference's own fp16-autocast
-run measures 2.7-3.1e-3 against its fp32 self, profiles/r05_reference_hosted.txt): per UNet forward rel-L2 <= 6e-3 (VERDICT r5 item 2's bar, 2x
-the reference's own fp16 error), 3-step samplers <= 8e-3, the 10-step config-1 miniature <= 1.5e-2."""
+Stated tolerance of the fp16 build = measured (round 6, profiles/r06_f16_first_contact.txt) + 25-40 %: per UNet forward rel-L2 <= 2.5e-3 (measured
+1.59e-3 full width, 1.69 / 1.78e-3 at 64 channels, 1.67e-3 on the full-size CFG step; profiles/r06_error_budget.txt predicted 1.5e-3; the
+reference's own fp16-autocast run is 2.7-3.1e-3 from its fp32 self, profiles/r05_reference_hosted.txt; VERDICT r5 item 2 asked for <= 6e-3),
+3-step samplers <= 2.4e-3 (1.0-1.8e-3), the 10-step config-1 miniature <= 1.8e-3 (1.35e-3). The bf16 build measures 1.2-1.3e-2 on the same goldens."""
 import json
 import os
 import subprocess
@@ -38,22 +39,22 @@ def test_f16_process_loads_the_f16_library(f16):
 def test_f16_kernels_vs_torch_fp32(f16):
     """Same fp16-rounded inputs, fp32 torch reference: what is left is the output rounding (2^-11 relative, rms ~ 2^-12.3 = 2e-4) and, for the
     attention, the bf16 numerators P and bf16 V (the zero-base softmax keeps bf16's exponent range in both builds)."""
-    assert f16["linear"] <= 4e-4 and f16["linear_alt_qk"] <= 4e-4, f16
-    assert f16["linear_alt_v"] <= 3e-3, f16            # the V block leaves as bf16 (2^-9 relative rounding: rms 1.6e-3)
-    assert f16["attn_spatial"] <= 4e-3 and f16["attn_temporal"] <= 4e-3, f16
-    assert f16["groupnorm_silu"] <= 4e-4, f16
+    assert f16["linear"] <= 3e-4 and f16["linear_alt_qk"] <= 3e-4, f16            # measured 2.07e-4
+    assert f16["linear_alt_v"] <= 2.2e-3, f16          # the V block leaves as bf16 (2^-9 relative rounding: rms 1.65e-3 measured)
+    assert f16["attn_spatial"] <= 2.2e-3 and f16["attn_temporal"] <= 1.6e-3, f16   # measured 1.66e-3 / 1.20e-3
+    assert f16["groupnorm_silu"] <= 3e-4, f16       # measured 2.08e-4
 
 
 def test_f16_unet_vs_reference_golden(f16):
     for k in ("unet_tiny_t5", "unet_tiny_t25", "unet_full_t5"):
-        assert f16[k]["finite"] and f16[k]["rel_l2"] <= 6e-3 and f16[k]["max_rel"] <= 3e-2, (k, f16[k])
+        assert f16[k]["finite"] and f16[k]["rel_l2"] <= 2.5e-3 and f16[k]["max_rel"] <= 3.5e-3, (k, f16[k])
 
 
 def test_f16_full_size_cfg_step_vs_oracle_checksums(f16):
-    assert f16["full_size_step"]["finite"] and f16["full_size_step"]["rel_l2"] <= 6e-3, f16["full_size_step"]
+    assert f16["full_size_step"]["finite"] and f16["full_size_step"]["rel_l2"] <= 2.2e-3, f16["full_size_step"]
 
 
 def test_f16_samplers_vs_reference_golden(f16):
     for name, r in f16["sampler"].items():
-        assert r <= 8e-3, (name, r)
-    assert f16["config1_miniature"] <= 1.5e-2, f16["config1_miniature"]
+        assert r <= 2.4e-3, (name, r)
+    assert f16["config1_miniature"] <= 1.8e-3, f16["config1_miniature"]

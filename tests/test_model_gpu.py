@@ -1,9 +1,12 @@
 """End-to-end parity of the MI355X path against the REAL reference's outputs (tests/golden/, produced by
 oracle/make_golden.py on CPU fp32) through the reference-compatible class API.
 
-Stated tolerance (bf16 storage + fp32 accumulate vs the fp32 reference; the reference's own fp16-autocast path has the
-same order of error): per UNet forward  rel-L2 <= 2.5e-2 and max|err| <= 8e-2 * max|ref|;  after a 3-step CFG sampler
-run  rel-L2 <= 4e-2."""
+Stated tolerance of the bf16 build (bf16 storage of activations AND weights, fp32 accumulation, against the fp32 reference). The bounds are
+the values measured in round 6 (profiles/r06_gpu_suite_parity_lines.txt; every reduction runs in a fixed order, so a run reproduces them bit for
+bit) plus 25 %, one bound per case -- VERDICT r5 item 2 (iii): per UNet forward rel-L2 <= 1.65e-2 and max|err| <= 2.2e-2 max|ref|; 3-step samplers
+per guider (BOUNDS below). Where the 1.2e-2 comes from: profiles/r06_error_budget.txt -- bf16 weights alone are 6.3e-3, the bf16 residual stream
+8.5e-3, bf16 GEMM operands 5.3e-3 (root-sum-square 1.19e-2): it is the format's floor, not a kernel's. The fp16-storage build of the same kernels
+(the reference's own autocast width) measures 1.6e-3 on the same goldens: tests/test_f16_gpu.py."""
 import os
 
 import pytest
@@ -47,7 +50,7 @@ def check_unet(net, shapes, g, tag):
     r, mx = rel_l2(out, ref), ((out - ref).abs().max() / ref.abs().max()).item()
     print(f"[parity] {tag}: rel-L2 {r:.4e}  max-abs/max-ref {mx:.4e}")
     assert torch.isfinite(out).all()
-    assert r <= 2.5e-2 and mx <= 8e-2, f"{tag}: rel-L2 {r:.3e}, max-rel {mx:.3e}"
+    assert r <= 1.65e-2 and mx <= 2.2e-2, f"{tag}: rel-L2 {r:.3e}, max-rel {mx:.3e}"   # measured 1.21-1.34e-2 / 1.60-1.67e-2
 
 
 @pytest.mark.parametrize("tag", ["t5", "t25"])
@@ -77,9 +80,9 @@ def test_full_size_cfg_step_vs_oracle_checksums():
     72 x 128, the shipped 1.65 B-parameter network with seeded non-zero weights) on the HIP path against the checksum set the CPU fp32 oracle
     produced for exactly these inputs (tools/make_full_size_checksums.py -> tests/golden/full_size_step_checksums.json: per frame mean, rms
     and 64 values at seeded positions; the oracle itself is pinned to the reference by tests/test_oracle_cpu.py). Stated tolerance, bf16
-    storage / fp32 accumulation through ~100 layers: per frame |mean - ref| <= 2e-2 rms, rms within 2 %, every sampled value within
+    storage / fp32 accumulation through ~100 layers: per frame |mean - ref| <= 1e-2 rms, rms within 1 %, every sampled value within
     8e-2 rms + 2e-2 |ref| (six standard deviations of the measured 1.3e-2 error level: 3200 samples), and the relative L2 error over all
-    samples <= 2.5e-2 (the per-forward bound of this file). Measured in round 4: 1.30e-2, worst frame mean 4.6e-3 rms, rms 1.7e-3."""
+    samples <= 1.65e-2 (the per-forward bound of this file). Measured in round 6: 1.287e-2, worst frame mean 4.8e-3 rms, rms 1.8e-3."""
     import json
     from oracle.make_golden import unet_inputs
     from tools.make_full_size_checksums import H, NS, SEED, SIGMA, T, W, sample_positions
@@ -109,7 +112,7 @@ def test_full_size_cfg_step_vs_oracle_checksums():
     rel = (num / den) ** 0.5
     print(f"[full-size CFG step] N=50 72x128 full width: sampled rel-L2 {rel:.3e}; worst frame mean {worst['mean']:.2e} rms, rms {worst['rms']:.2e}, "
           f"sample {worst['sample']:.2f} of its tolerance")
-    assert worst["mean"] <= 2e-2 and worst["rms"] <= 2e-2 and worst["sample"] <= 1.0 and rel <= 2.5e-2, (rel, worst)
+    assert worst["mean"] <= 1e-2 and worst["rms"] <= 1e-2 and worst["sample"] <= 1.0 and rel <= 1.65e-2, (rel, worst)
 
 
 def test_sampler_and_denoiser_vs_reference_golden():
@@ -137,6 +140,8 @@ def test_sampler_and_denoiser_vs_reference_golden():
     def closure(x, sigma, cond, cond_mask):  # the reference's own closure shape (sample_utils.py:314-315)
         return den(wrapper, x, sigma, cond, cond_mask)
 
+    # measured (round 6, both paths within 2e-4 of each other): vanilla 1.342e-2, linear 1.264 / 1.279e-2, triangle 1.270e-2, identity 7.80e-3
+    BOUNDS = {"vanilla": 1.68e-2, "linear": 1.6e-2, "triangle": 1.59e-2, "identity": 9.8e-3}
     for name, cfg in cfgs.items():
         for path, dn in (("fused", fused), ("generic", closure)):
             noise = w["noise"].clone().cuda()
@@ -144,7 +149,7 @@ def test_sampler_and_denoiser_vs_reference_golden():
                                 cond_mask=w["cond_mask"].cuda()).cpu()
             r = rel_l2(out, g[name])
             print(f"[parity] sampler {name}/{path}: rel-L2 {r:.4e}")
-            assert r <= 4e-2, f"sampler {name}/{path}: rel-L2 {r:.3e}"
+            assert r <= BOUNDS[name], f"sampler {name}/{path}: rel-L2 {r:.3e} > {BOUNDS[name]:.3e}"
             # the reference scales the caller's noise tensor in place (sampling.py:36)
             assert torch.allclose(noise.cpu(), g[name + "_noise_after"], rtol=1e-5, atol=1e-5)
             # cond frames are replaced exactly at the end (sampling.py:122)
@@ -155,7 +160,7 @@ def test_sampler_and_denoiser_vs_reference_golden():
                                      cond_frame=w3["cond_frame"].cuda(), cond_mask=w3["cond_mask"].cuda()).cpu()
     r = rel_l2(out, g["rollout3"])
     print(f"[parity] sampler rollout3 (3 cond frames, triangle): rel-L2 {r:.4e}")
-    assert r <= 4e-2 and torch.equal(out[:3], w3["cond_frame"][:3])
+    assert r <= 1.0e-2 and torch.equal(out[:3], w3["cond_frame"][:3])   # measured 8.03e-3
     # plain Denoiser.forward boundary
     sig = torch.full((T,), 5.0)
     x2, s2, c2, m2 = guiders.VanillaCFG(2.5).prepare_inputs((w["noise"] * 5.0).cuda(), sig.cuda(), cuda(w["c"]), w["cond_mask"].cuda(),
@@ -163,7 +168,7 @@ def test_sampler_and_denoiser_vs_reference_golden():
     d = den(wrapper, x2, s2, c2, m2).cpu()
     r = rel_l2(d, g["denoiser_out"])
     print(f"[parity] denoiser: rel-L2 {r:.4e}")
-    assert r <= 2.5e-2
+    assert r <= 1.6e-2   # measured 1.284e-2
 
 
 def test_stochastic_sampler_step_vs_reference_golden():
@@ -191,12 +196,13 @@ def test_stochastic_sampler_step_vs_reference_golden():
     assert next(draws, None) is None, "the sampler did not draw noise on exactly the steps the reference did"
     r = rel_l2(out, g["out"])
     print(f"[parity] stochastic sampler (s_churn {prm['s_churn']}, 4 steps, injected reference draws): rel-L2 {r:.4e}")
-    assert torch.isfinite(out).all() and r <= 4e-2 and torch.equal(out[0], w["cond_frame"][0])
+    assert torch.isfinite(out).all() and r <= 1.9e-2 and torch.equal(out[0], w["cond_frame"][0])   # measured 1.505e-2
 
 
 def test_config1_miniature_25_frames_10_steps_vs_reference_golden():
     """BASELINE config 1 in miniature: 1 cond frame -> 25 frames, 10 EDM steps, VanillaCFG 2.5, against the real reference sampler's
-    output (CPU fp32, stored fp16). Ten Euler steps compound the per-step bf16 error; tolerance rel-L2 <= 6e-2."""
+    output (CPU fp32, stored fp16). Measured 1.04e-2 (ten Euler steps do not compound the per-step bf16 error: each step contracts towards the
+    denoised estimate); tolerance rel-L2 <= 1.3e-2."""
     from vista_amd import synth
     from vista_amd.modules.diffusionmodules.denoiser import Denoiser
     from vista_amd.modules.diffusionmodules.sampling import FusedDenoiser
@@ -212,7 +218,7 @@ def test_config1_miniature_25_frames_10_steps_vs_reference_golden():
             cond_frame=w["cond_frame"].cuda(), cond_mask=w["cond_mask"].cuda()).cpu()
     r = rel_l2(out, g["out"].float())
     print(f"[parity] config-1 miniature (25 frames, 10 steps, CFG 2.5): rel-L2 {r:.4e}")
-    assert torch.isfinite(out).all() and r <= 6e-2 and torch.equal(out[0], w["cond_frame"][0])
+    assert torch.isfinite(out).all() and r <= 1.3e-2 and torch.equal(out[0], w["cond_frame"][0])
 
 
 def test_unet_properties_batch_and_determinism():
@@ -259,7 +265,7 @@ def test_unet_full_latent_size_tiny_width_vs_oracle():
     out = net(x8.cuda(), timesteps=ts.cuda(), context=ctx.cuda(), y=y.cuda(), cond_mask=mask.cuda(), num_frames=T).cpu()
     r, mx = rel_l2(out, ref), ((out - ref).abs().max() / ref.abs().max()).item()
     print(f"[parity] tiny-width UNet at the full 25x72x128 latent vs oracle: rel-L2 {r:.4e} max-rel {mx:.4e}")
-    assert torch.isfinite(out).all() and r <= 2.5e-2 and mx <= 8e-2
+    assert torch.isfinite(out).all() and r <= 1.65e-2 and mx <= 2.3e-2   # measured 1.302e-2 / 1.84e-2
 
 
 def test_product_path_refuses_cpu():
@@ -312,7 +318,7 @@ def test_sampler_full_50_step_schedule_vs_oracle():
     """The WHOLE 50-step EDM schedule end to end (VERDICT r1 missing #6; the longest chain before was 10 steps): 64-channel network,
     T=5, latent 16x32, VanillaCFG 2.5, fused path, against the CPU oracle's 50-step run (computed here, ~1 min on the host).
     Each step is a contraction towards the denoised estimate (x <- x + (sigma_next/sigma - 1)(x - D(x))), so per-step bf16 noise does
-    not grow without bound (measured 8.2e-3, below one forward's 1.3e-2); stated tolerance rel-L2 <= 2.5e-2, measured value appended to gpurun_out/parity_50step.json."""
+    not grow without bound (measured 8.16e-3, below one forward's 1.3e-2); stated tolerance rel-L2 <= 1.02e-2 (measured + 25 %), measured value appended to gpurun_out/parity_50step.json."""
     import json
     net, _ = tiny_unet()
     w, want, T, steps = oracle_50_step()
@@ -322,7 +328,7 @@ def test_sampler_full_50_step_schedule_vs_oracle():
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(d):
         json.dump({"steps": steps, "rel_l2": r}, open(os.path.join(d, "parity_50step.json"), "w"))
-    assert torch.isfinite(got).all() and r <= 2.5e-2 and torch.equal(got[0], w["cond_frame"][0])
+    assert torch.isfinite(got).all() and r <= 1.02e-2 and torch.equal(got[0], w["cond_frame"][0])
 
 
 def test_hipgraph_replay_of_the_unet_forward_is_bitwise_the_eager_loop(monkeypatch):
