@@ -40,7 +40,9 @@ typedef struct VkGemmDesc {
                             960), 7 = 256x320 eight-wave pipelined kernel (DENSE / CONV3X3 / TEMPORAL3 without halos x LINEAR, bf16 out,
                             DENSE x GEGLU; bitwise equal to 4). A variant that does not take the problem falls back to the launcher's choice.
                             Weight rows are zero-padded to max(ceil256(N), ceil320(N)) so every variant reads whole tiles.
-                            + 64 (with variant 0): apply the tail-split rule of vk_gemm_tail_split (an A/B option, off by default).                   */
+                            + 64 (with variant 0): apply the tail-split rule of vk_gemm_tail_split (an A/B option, off by default).
+                            + 16: the four-wave pipelined 128x320 kernel, two workgroups per CU (DENSE x LINEAR / GEGLU, 16-bit out; bitwise equal
+                            to 7; an A/B option of round 6, off by default) wherever it takes the problem and leaves the row-sum slabs alone.        */
     const void* halo_prev; /* TEMPORAL3, frame-sharded runs: bf16 [clips][S][Cin] frame preceding / following the local frame range   */
     const void* halo_next; /* (from the neighbour rank); NULL = the conv's zero padding at the window ends                               */
     void* splitk_ws;     /* optional fp32 workspace for split-K of small-M, deep-K LINEAR problems (NULL = never split); must not be  */

@@ -656,6 +656,74 @@ def test_gemm_pipe_is_bitwise_the_sixteen_wave_kernel(kind, n, H, W, C):
     assert torch.equal(o7, o4), "pipelined and sixteen-wave kernels must agree bit for bit"
 
 
+@pytest.mark.parametrize("kind", ["dense+res+stats", "dense_strided_A", "qkv_lnfold", "ff_out+blend", "geglu_lnfold", "dense_K_32_mod_64"])
+@pytest.mark.parametrize("n,H,W,C", [(3, 20, 24, 320), (5, 9, 13, 640), (9, 36, 64, 320)])   # ragged last tile, tiles spanning images, > 512 tiles
+def test_gemm_pipe2_is_bitwise_the_pipelined_kernel(kind, n, H, W, C):
+    """gemm_pipe2.hip (VkGemmDesc.tile_cfg bit 4: four waves, 128x320 tiles, TWO workgroups per CU, 32-deep K-steps, activation ring of three and
+    weight ring of two stages, one counted vmcnt wait per K-step) against the eight-wave 256x320 pipelined kernel (tile_cfg 7), bit for bit incl. the
+    row-sum slabs, for every DENSE epilogue it takes, and against torch fp32. An A/B option of round 6 (off by default: profiles/r06_gemm_pipe2.txt).
+    Reference call sites: attention.py:85-110 (GEGLU / FeedForward), :344-346,421 (projections)."""
+    ops = _ops()
+    S = H * W
+    M = n * S
+    x = rnd(M, C)
+    res = rnd(M, C, seed=3)
+    rv = rnd(n, C, seed=5).float()
+    if kind == "dense+res+stats":
+        w, b = rnd(C, C, scale=C ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda: ops.linear(x, pw, res1=res, rowvec=rv, rows_per_vec=S, emit_stats=True)  # noqa: E731
+        ref = x.float() @ w.float().t() + b + res.float() + rv.repeat_interleave(S, 0)
+    elif kind == "dense_strided_A":
+        wide = rnd(M, 3 * C, seed=11)
+        xs = wide[:, C:2 * C]
+        w, b = rnd(C, C, scale=C ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda: ops.linear(xs, pw, res1=res)  # noqa: E731
+        ref = xs.float() @ w.float().t() + b + res.float()
+    elif kind == "dense_K_32_mod_64":   # K = C + 64 is a multiple of 64 (the ABI's rule); an odd count of 64-deep steps = 2 (mod 4) 32-deep ones: both ring parities end the loop
+        xk = rnd(M, C + 64, seed=13)
+        w, b = rnd(C, C + 64, scale=C ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda: ops.linear(xk, pw)  # noqa: E731
+        ref = xk.float() @ w.float().t() + b
+    elif kind == "qkv_lnfold":
+        nrm = _Norm(C, 7)
+        w, b = rnd(3 * C, C, scale=C ** -0.5, seed=1), rnd(3 * C, seed=2).float()
+        pw = ops.pack_linear(w, b, ln=nrm)
+        st = ops.rowstats(x)
+        fn = lambda: ops.linear(x, pw, ln=st)  # noqa: E731
+        ref = _ln_ref(x, nrm.weight, nrm.bias) @ w.float().t() + b
+    elif kind == "ff_out+blend":
+        h4 = rnd(M, 4 * C, seed=9)
+        w, b = rnd(C, 4 * C, scale=(4 * C) ** -0.5, seed=1), rnd(C, seed=2).float()
+        pw = ops.pack_linear(w, b)
+        fn = lambda: ops.linear(h4, pw, res1=res, alpha=0.4, res2=x, rowvec2=rv, beta=0.6, rows_per_vec=S)  # noqa: E731
+        ref = 0.4 * (h4.float() @ w.float().t() + b + res.float()) + 0.6 * (x.float() + rv.repeat_interleave(S, 0))
+    else:
+        nrm = _Norm(C, 7)
+        w, b = rnd(8 * C, C, scale=C ** -0.5, seed=1), rnd(8 * C, seed=2).float()
+        pw = ops.pack_geglu(w, b, ln=nrm)
+        st = ops.rowstats(x)
+        fn = lambda: ops.linear(x, pw, ln=st)  # noqa: E731
+        a, g = (_ln_ref(x, nrm.weight, nrm.bias) @ w.float().t() + b).chunk(2, dim=-1)
+        ref = a * F.gelu(g)
+    outs = {}
+    for cfg in (16, 7):
+        ops.TILE_CFG = cfg
+        try:
+            outs[cfg] = fn()
+        finally:
+            ops.TILE_CFG = 0
+    o2, o7 = outs[16], outs[7]
+    if isinstance(o2, tuple):
+        (o2, s2), (o7, s7) = o2, o7
+        assert s2.parts == s7.parts and torch.equal(s2.t, s7.t), "row-sum slabs differ"
+        _check_stats(s2, o2)
+    close(o2.reshape(ref.shape), ref, f"gemm_pipe2 {kind}")
+    assert torch.equal(o2, o7), "the two-per-CU and the eight-wave pipelined kernels must agree bit for bit"
+
+
 @pytest.mark.parametrize("kind", ["qkv_lnfold", "dense_K4N+res+stats", "conv3x3+emb+res", "conv_t3+blend"])
 @pytest.mark.parametrize("n,H,W", [(29, 36, 64), (30, 35, 64)])   # 261 row tiles of 256 (5 in the last round); 262.5 (ragged last tile)
 def test_gemm_tail_split_and_row_ranges_are_bitwise(kind, n, H, W):

@@ -356,7 +356,7 @@ def test_hipgraph_replay_of_the_unet_forward_is_bitwise_the_eager_loop(monkeypat
     # stream, one split-K workspace per device) ...
     assert len(made) >= 2 and made[-1]._graph is made[-2]._graph and len(net.__dict__["_hipgraph_cache"]) == 1
     from vista_amd import ops
-    assert len(FusedLoop._WARM_STREAMS) == 1 and len(ops._GRAPH_WS) == 1
+    assert len(FusedLoop._WARM_STREAMS) == 1 and len(ops._GRAPH_TLS.ws) == 1 and made[-1]._graph["ws"] is ops.graph_workspace_tensor()
     # ... with the conditioning as static buffers: another window through the SAME graph equals its own eager run
     w2 = dict(w)
     w2["c"] = {k: (v * 0.5 if k == "crossattn" else v) for k, v in w["c"].items()}

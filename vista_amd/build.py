@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libvista_hip.so")
 # attention.hip: the pipelined spatial kernel's row-sum adds must stay single v_add_f32 (packed they are gathered at the end of a unit and keep
 # its sixteen exponentials live: spills in a loop that is 256 registers wide)
 EXTRA_FLAGS = {"ff_fused.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"]}
-SOURCES = ["gemm.hip", "gemm_pipe.hip", "gemm_stream.hip", "gemm_fp8.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "gemm_pipe.hip", "gemm_pipe2.hip", "gemm_stream.hip", "gemm_fp8.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 
 
 def hipcc():

@@ -42,6 +42,9 @@
 extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d);
 extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream, int ksplit);
 extern "C" int vk_gemm_pipe_gnstat_ok(const VkGemmDesc* d, int ksplit);
+// gemm_pipe2.hip: the four-wave pipelined 128x320 variant, two workgroups per CU (tile_cfg bit 4 / VISTA_GEMM_PIPE2: an A/B option, off by default)
+extern "C" int vk_gemm_pipe2_fit(const VkGemmDesc* d);
+extern "C" int vk_gemm_pipe2_launch(const VkGemmDesc* d, void* stream);
 
 namespace {
 
@@ -448,6 +451,9 @@ inline TileChoice choose_tile(const VkGemmDesc* d) {
     static const int tile5_max_k = [] { const char* e = getenv("VISTA_TILE5_MAXK"); return e ? atoi(e) : TILE5_MAX_K_DEFAULT; }();
     const int amode = d->amode, epi = d->epi;
     const int force = d->tile_cfg & 7;  // 0 = auto (tests / tuning force a variant)
+    // tile_cfg bit 4 (alone): the two-per-CU pipelined kernel is asked for. Where it takes the problem the answer is the 320-column, two-wave-column
+    // geometry of variant 7 without K slices (row-sum slabs, vk_gemm_tile_choice), whatever the size rules below would pick; launch() then routes it.
+    if ((d->tile_cfg & 16) && force == 0 && vk_gemm_pipe2_fit(d)) return {7, 1};
     int cfg = force;
     if (d->mx8_out) cfg = 4;  // MX-fp8 output lives in the LDS-staged epilogue of whole 320-column tiles (validate() checked N and mx8_cols)
     if (cfg == 5 && !cfg5_ok(d)) cfg = 4;
@@ -540,7 +546,7 @@ inline void tile_geometry(int cfg, int& bn, int& wn) {
 // rows [m_split, m_end) as a second launch of 128x160 tiles (four waves, two workgroups per CU: a quarter of the work per workgroup, all of
 // them resident at once) -- the same MFMA sequence per output element, the same row-sum slabs (160 columns each): bitwise the same result
 // as the single launch (tests/test_kernels_gpu.py::test_gemm_tail_split_and_row_ranges_are_bitwise). Returns the split row, 0 = no split.
-// MEASURED (round 5, profiles/r05_tail_split_experiment.txt) and NOT adopted: the split changes nothing (level-0 conv3x3 0.7239 vs 0.7245 ms,
+// MEASURED (round 5, profiles/r05_negative_results.txt section 1) and NOT adopted: the split changes nothing (level-0 conv3x3 0.7239 vs 0.7245 ms,
 // q|k|v 0.4602 vs 0.4626, temporal conv 0.318 vs 0.306; step 169.4 vs 169.5 ms). The eight tiles of the "eighth round" do not cost a round: alone
 // on the chip they run ~2.4x faster than a tile among 255 others (no HBM / L2 contention, and the clock is no longer held down by the power
 // of 256 busy CUs), which is about what the extra launch costs. The rule stays available as VISTA_GEMM_TAIL=<percent> (A/B hook), default off.
@@ -560,9 +566,31 @@ inline int tail_split_row(const VkGemmDesc* d, const TileChoice& t) {
     return m_split;
 }
 
+// The two-per-CU pipelined kernel (gemm_pipe2.hip) instead of the launcher's choice `t`? Only where it leaves the row-sum slab geometry alone (the
+// 320-column variants 4 / 5 / 7 all write one slab per 160 columns, as it does; GEGLU launches emit none) and never for a split-K launch.
+// tile_cfg bit 4 forces it (tests / probes); VISTA_GEMM_PIPE2 = 1 (LINEAR) | 2 (GEGLU) | 3 (both) turns it on for whole-round problems with
+// K <= VISTA_PIPE2_MAXK (default 1280). Off by default: profiles/r06_gemm_pipe2.txt.
+inline bool pipe2_wanted(const VkGemmDesc* d, const TileChoice& t) {
+    static const int mode = [] { const char* e = getenv("VISTA_GEMM_PIPE2"); return e ? atoi(e) : 0; }();
+    static const int maxk = [] { const char* e = getenv("VISTA_PIPE2_MAXK"); return e ? atoi(e) : 1280; }();
+    const bool forced = (d->tile_cfg & 16) != 0;
+    if (!forced && !(mode & (d->epi == EPI_GEGLU ? 2 : 1))) return false;
+    if (t.ksplit != 1 || d->amode != AMODE_DENSE || d->out_f32) return false;
+    if (d->epi == EPI_LINEAR && t.cfg != 4 && t.cfg != 5 && t.cfg != 7) return false;
+    if (!forced) {
+        if ((d->tile_cfg & 7) != 0 || d->K > maxk) return false;
+        const long long tiles = (long long)((d->m_end - d->m_begin + 127) / 128) * (d->N / 320);
+        if (tiles < 512) return false;   // less than one round of two workgroups per CU: the small-problem rules stay
+    }
+    return vk_gemm_pipe2_fit(d) != 0;
+}
+
 template <int AMODE, int EPI, bool OUT_F32>
 int launch(const VkGemmDesc* d, hipStream_t stream) {
     const TileChoice t = choose_tile(d);
+    if constexpr (AMODE == AMODE_DENSE && (EPI == EPI_LINEAR || EPI == EPI_GEGLU) && !OUT_F32) {
+        if (pipe2_wanted(d, t)) return vk_gemm_pipe2_launch(d, stream);
+    }
     if constexpr (EPI == EPI_LINEAR && !OUT_F32 && (AMODE == AMODE_DENSE || AMODE == AMODE_CONV3X3 || AMODE == AMODE_TEMPORAL3)) {
         if (const int m_split = tail_split_row(d, t)) {
             VkGemmDesc head = *d, tail = *d;
@@ -599,7 +627,7 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
 
 inline int validate(const VkGemmDesc* d) {
     if (!d || !d->A || !d->Wt || !d->out) return VK_EINVAL;
-    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & ~64) > 7) return VK_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || (d->K % BK) != 0 || (d->N % 4) != 0 || d->tile_cfg < 0 || (d->tile_cfg & ~(64 | 16)) > 7) return VK_EINVAL;
     if (d->m_begin < 0 || d->m_end < 0 || d->m_end > d->M || (d->m_end != 0 && d->m_begin >= d->m_end) || (d->m_end == 0 && d->m_begin >= d->M)) return VK_EINVAL;
     if ((d->m_begin != 0 || (d->m_end != 0 && d->m_end != d->M)) && d->epi == EPI_TRANS) return VK_EINVAL;   // (row ranges: LINEAR / GEGLU)
     if (d->amode != AMODE_DENSE && (d->Cin <= 0 || (d->Cin % BK) != 0)) return VK_EINVAL;
@@ -634,6 +662,7 @@ extern "C" int vk_gemm_stream_fit(const VkGemmDesc* d);
 extern "C" int vk_gemm_stream_launch(const VkGemmDesc* d, void* stream);
 static int stream_fit(const VkGemmDesc* d) {
     static const bool on = [] { const char* e = getenv("VISTA_GEMM_STREAM"); return !e || atoi(e) != 0; }();   // A/B hook: 0 = tiled kernels only
+    if (d->tile_cfg & 16) return 0;   // (the two-per-CU pipelined kernel was asked for)
     return (on || (d->tile_cfg & 7) == 6) ? vk_gemm_stream_fit(d) : 0;
 }
 

@@ -560,8 +560,10 @@ int gn_apply(const void* x, const void* x2, int C1, void* y, const float* gamma,
     const int tok_per_wg = g.tok;
     dim3 grid(g.nchunks, n_img);
     // Non-temporal hints for tensors that do not fit the 256 MiB Infinity Cache anyway (levels 0 and 1 at the BASELINE window: 295 / 147 MB): the
-    // input is dead after this pass and the output is too large to survive until its consumer, so neither should evict what the neighbouring
-    // kernels keep there. Same box, alternated processes (tools/gn_nt_ab.py, profiles/r05_gn_nontemporal_ab.txt): GroupNorm (statistics + fold +
+    // output is too large to survive until its consumer, and the input -- dead after this pass at most call sites; the ResBlock's first norm input
+    // (re-read as the skip of conv2) and the transformer's opening norm input (the block residual) are read once more, much later, from HBM either
+    // way at this size -- should not evict what the neighbouring kernels keep there. The stores carry most of the gain, the load hint the rest
+    // (gn+conv 0.958 stores only / 0.940 both); the whole-step A/B (which contains the two re-reading call sites) is the one that decided. Same box, alternated processes (tools/gn_nt_ab.py, profiles/r05_gn_nontemporal_ab.txt): GroupNorm (statistics + fold +
     // apply) 0.190 -> 0.149 ms at level 0, 0.082 -> 0.078 at level 1, unchanged at level 2; GroupNorm + the 3x3 convolution that reads it 0.958 ->
     // 0.940 / 0.853 -> 0.843 / 0.783 -> 0.79 (level 2 fits the cache: no hint there); step 164.1 -> 163.6 ms. Bitwise the same output.
     // VISTA_GN_NT = 0..3 forces (bit 0 = loads, bit 1 = stores) for an A/B; unset = the size rule.

@@ -230,6 +230,10 @@ class FusedLoop:
                 with torch.cuda.stream(side):   # eager warm-up off the capture: weight packs and caches get built here
                     fwd()
                 torch.cuda.current_stream().wait_stream(side)
+                # the key is taken AFTER the warm-up: a forward that finds a switch flipped since its packs were built calls invalidate_packed()
+                # itself and bumps the generation -- the key taken before it would be stale at once and the next window would re-capture for nothing
+                g["wkey"] = (_att.pack_generation(),) + tuple((id(q), _att.Packable._param_version(q)) for q in unet.parameters())
+                g["ws"] = ops.graph_workspace_tensor()   # the split-K workspace the captured launches point at lives as long as the graph does
                 g["graph"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g["graph"]):
                     g["out"] = fwd()

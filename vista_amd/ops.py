@@ -195,29 +195,33 @@ class _SplitKTLS(threading.local):
 _SPLITK_WS = _SplitKTLS()
 
 
-_GRAPH_WS = {}        # (device, host thread) -> the ONE workspace of every hipGraph warm-up / capture / replay of that thread on that device
-
-
 class _GraphTLS(threading.local):
+    """Per host thread: `depth` > 0 inside graph_workspace() (then _splitk_workspace hands out the graph workspace instead of a per-stream buffer);
+    `ws` = {device: the ONE workspace of every hipGraph warm-up / capture of THIS thread on that device}. Thread-local like _SplitKTLS, so a worker
+    thread's buffer goes with the thread (a module-level dict keyed by thread ident leaked 160 MiB per thread and let a new thread inherit
+    a dead thread's buffer) -- unless a captured graph still needs it: sampling.FusedLoop keeps graph_workspace_tensor() in its graph-cache entry,
+    because the graph's split-K launches have the pointer baked in. A graph may be replayed from any thread, one replay at a time."""
+
     def __init__(self):
-        self.depth = 0   # > 0 inside graph_workspace() ON THIS THREAD: _splitk_workspace hands out _GRAPH_WS instead of a per-stream buffer
+        self.depth = 0
+        self.ws = {}
 
 
 _GRAPH_TLS = _GraphTLS()
 
 
 class graph_workspace:
-    """Context manager for hipGraph warm-up + capture (sampling.FusedLoop): every split-K GEMM enqueued inside uses ONE per-device workspace,
-    allocated here -- OUTSIDE any capture, so it belongs to the ordinary caching allocator and not to a graph's private pool -- instead of a
-    fresh 160 MB buffer per (thread, stream). Graph replays run on the launch stream one after the other, so they may share it; eager work on
-    other streams keeps its per-stream buffers."""
+    """Context manager for hipGraph warm-up + capture (sampling.FusedLoop): every split-K GEMM enqueued inside uses ONE workspace per (thread,
+    device), allocated here -- OUTSIDE any capture, so it belongs to the ordinary caching allocator and not to a graph's private pool -- instead
+    of a fresh 160 MB buffer per (thread, stream). Graph replays run on the launch stream one after the other, so they may share it; eager work
+    on other streams keeps its per-stream buffers."""
 
     def __enter__(self):
-        key = (torch._C._cuda_getDevice(), threading.get_ident())   # thread ranks (tests) enqueue concurrently: one workspace each
-        if SPLITK_WS_BYTES and key not in _GRAPH_WS:
+        dev = torch._C._cuda_getDevice()
+        if SPLITK_WS_BYTES and dev not in _GRAPH_TLS.ws:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("ops.graph_workspace must be entered before the capture starts")
-            _GRAPH_WS[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{key[0]}")
+            _GRAPH_TLS.ws[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{dev}")
         _GRAPH_TLS.depth += 1
         return self
 
@@ -226,13 +230,19 @@ class graph_workspace:
         return False
 
 
+def graph_workspace_tensor():
+    """The calling thread's graph workspace on the current device (None before the first graph_workspace()): a graph-cache entry holds a reference to
+    it for as long as its graph lives."""
+    return _GRAPH_TLS.ws.get(torch._C._cuda_getDevice())
+
+
 def _splitk_workspace(stream):
     """One workspace per (device, stream) of each host thread: launches on one stream are ordered, so they may share it; GEMMs in flight on
     different streams must not (include/vista_hip.h, VkGemmDesc.splitk_ws), and thread ranks (tests) share a stream but enqueue
     concurrently. Held in thread-local storage, so a worker thread's buffers are released when the thread exits. Inside
-    graph_workspace() (hipGraph warm-up / capture) the device's single graph workspace is used instead."""
+    graph_workspace() (hipGraph warm-up / capture) the thread's single graph workspace of the device is used instead."""
     if _GRAPH_TLS.depth > 0:
-        return _GRAPH_WS[(torch._C._cuda_getDevice(), threading.get_ident())]
+        return _GRAPH_TLS.ws[torch._C._cuda_getDevice()]
     key = (torch._C._cuda_getDevice(), stream.value)
     ws = _SPLITK_WS.ws.get(key)
     if ws is None:
