@@ -42,8 +42,16 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // GN_CPG != 0: an instantiation whose LINEAR epilogue also emits the GroupNorm statistics of the output (VkGemmDesc.gnstat_out, gemm_common.h) for
 // groups of GN_CPG channels with GN_NRES residual tensors; kernels of their own so that the others keep their register allocation, and one body
 // each (244 VGPRs, no scratch; any two bodies in one kernel spill)
-template <int AMODE, int EPI, bool NT_A, bool SPLIT, int GN_CPG = 0, int GN_NRES = 0>
+// PF (round 6, DENSE loader): L2 prefetch of the activation rows TWO K-steps ahead. The activation pieces of a dense K-step come from HBM / the Infinity
+// Cache (~2 us under load) but are issued only one K-step (~1.3 us of MFMAs) before the barrier that needs them: the phase timers show 450-800 of a
+// 3700-4600-tick K-step period waiting on the wave's own pieces (profiles/r04_gemm_pipe.txt section 3, r06_gemm_pipe2.txt), which the convolution loaders
+// (taps re-read from L2) do not have. One plain 4-byte buffer_load per lane and K-step -- thread t touches the 64-byte half (t & 1) of row (t >> 1)'s
+// 128-byte K-step segment, destination a dummy register -- issued right AFTER the nine pieces of K-step kt + 1 pulls K-step kt + 2's lines into the
+// XCD's L2, so that the LDS-DMA of the next iteration finds them there. It is the youngest vector-memory operation at the K-step barrier, whose wait
+// therefore becomes vmcnt(1) + a raw s_barrier (__syncthreads() would wait for it: vmcnt(0)). No arithmetic changes: results are bitwise the same.
+template <int AMODE, int EPI, bool NT_A, bool SPLIT, int GN_CPG = 0, int GN_NRES = 0, bool PF = false>
 __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, const int ksplit) {
+    static_assert(!PF || AMODE == AMODE_DENSE, "the L2 prefetch is written for the dense loader");
     constexpr int LN_OFF = 2 * PSTAGE, EV_OFF = LN_OFF + PBM * 8;
     constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
     constexpr bool WALK = (EPI == EPI_GEGLU);   // persistent tile walk (pipe_launch); the LINEAR instantiations are compiled as one tile per workgroup
@@ -185,6 +193,17 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
     // q-th piece of a K-step in issue order: the activation pieces first (they are the ones that may come from HBM)
     auto dma_q = [&](const int q, const int stage) __attribute__((always_inline)) { dma_piece(q < PAP ? PWP + q : q - PAP, stage); };
 
+    // PF: the lane's offset into the tile's activation rows; the dummy destination stays a live register until the kernel ends (a load still in
+    // flight must not land in a register the allocator has handed to something else)
+    unsigned pf_dummy = 0;
+    const unsigned pf_voff = ((unsigned)(tid >> 1) * (unsigned)p.lda + (unsigned)(tid & 1) * 32u) * 2u;
+    auto prefetch = [&](const bool live) __attribute__((always_inline)) {
+        if constexpr (PF) {
+            const unsigned v = live ? pf_voff : P_OOB;   // (rows past M and K-steps past the tile: out of range = no memory access)
+            asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(pf_dummy) : "v"(v), "s"(ra), "s"((unsigned)kb) : "memory");
+        }
+    };
+
     f32x16_t acc[PFX][PFY];
 
     // fragment addresses: weights rows wn*160 + 32*f + l31 of sW, activation rows wm*64 + 32*f + l31 of sA, k-substep ks = chunk (2*ks + lh) ^ sw
@@ -283,6 +302,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             PIPE_SB();
             mma_dma(xa, ya, st ^ 1);
             dma_next();
+            prefetch(kt + 2 < nk);   // (kb now names K-step kt + 2)
             PIPE_SB();
             load_frags(st, 2, xa, ya);
             PIPE_SB();
@@ -295,8 +315,13 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
 #ifdef PIPE_TIMING   // s_memtime stamps around the barrier: own-DMA wait and barrier wait per K-step
             unsigned long long t1, t2, t3;
             asm volatile("s_waitcnt lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory");
-            asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
+            if (PF) asm volatile("s_waitcnt vmcnt(1)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t2) :: "memory");
 #endif
+            if constexpr (PF) {   // everything but the youngest operation (the prefetch) has landed; a raw barrier: __syncthreads() would add vmcnt(0)
+                asm volatile("s_waitcnt vmcnt(1)\n s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else
             __syncthreads();   // vmcnt(0): this wave's pieces of K-step kt + 1 have landed; lgkmcnt(0): its reads of stage st are done
 #ifdef PIPE_TIMING
             asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t3) :: "memory");
@@ -376,6 +401,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         __syncthreads();   // + vmcnt(0): the next tile's first K-step has landed
         st ^= 1;
     }
+    if constexpr (PF) asm volatile("" :: "v"(pf_dummy));   // (live until here: see its declaration)
 #ifdef PIPE_TIMING
     if (blockIdx.x == 8 && lane == 0 && p.splitk_ws) {   // per wave: [own-DMA wait, barrier wait, K-steps timed, K-loops, epilogues (+ next tile's setup), kernel] in s_memtime ticks
         unsigned long long tm_end;
@@ -414,6 +440,21 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
             else if (desc.N == 640) { if (nres == 0) VK_PIPE_GN(20, 0); else VK_PIPE_GN(20, 1); }
             else { if (nres == 0) VK_PIPE_GN(40, 0); else VK_PIPE_GN(40, 1); }
 #undef VK_PIPE_GN
+            VK_CHECK_LAUNCH();
+            return VK_OK;
+        }
+    }
+    if constexpr (AMODE == AMODE_DENSE) {
+        // L2 prefetch of the activation rows two K-steps ahead (template flag PF): where the rows are whole 128-byte lines (lda and the base pointer), the
+        // K-loop is long enough to have something to prefetch AND the launch is at most one round of tiles. Measured (profiles/r06_gemm_prefetch.txt): a
+        // launch that fills the chip for several rounds is bound by request throughput, not latency, and the second request per line costs 2-5 % (step +1 ms
+        // with the prefetch everywhere); an under-filled launch (the deep levels, every level of a frame-sharded rank) waits out the full memory latency in
+        // each K-step and gains 3-33 %. VISTA_GEMM_PF: unset = this rule, 1 = every dense launch, 0 = never (A/B hooks; bitwise the same results).
+        static const int pf_env = [] { const char* e = getenv("VISTA_GEMM_PF"); return e ? atoi(e) : -1; }();
+        const bool pf_want = pf_env < 0 ? ntiles <= 256 : pf_env != 0;
+        if (pf_want && d->K >= 3 * BK && (d->lda % 64) == 0 && (((size_t)d->A) & 127) == 0) {
+            if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, true, false, 0, 0, true>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
+            else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false, false, 0, 0, true>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
             VK_CHECK_LAUNCH();
             return VK_OK;
         }
