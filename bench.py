@@ -106,7 +106,8 @@ def cpu_baseline(net, T, H, W, seed):
     return {"value": 1.0 / est_s, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"six full-size pieces of the step timed in this run on the host ({cores} threads) through the ORACLE (oracle/vista_oracle.py: fp32 restatement "
                       f"of the reference, pinned to the reference's own modules by tests/test_oracle_cpu.py -- not the reference itself, which does not exist on "
-                      f"this box), one 25-frame clip each, network weights: "
+                      f"this box; its attention is the literal matmul / softmax / matmul walked in head slices of <= 2 GB of scores, where the reference's "
+                      f"shimmed xformers call would be one fused SDPA: a pessimistic baseline for the level-0 transformer piece), one 25-frame clip each, network weights: "
                       + "; ".join(f"{n}: {t:.1f} s, {f / 1e12:.2f} TFLOP" for n, t, f in pieces) +
                       f" -> {rate / 1e12:.3f} TFLOP/s blended; 2 clips x 5 such pairs per level are {100 * share:.0f} % of the step's {FLOP_PER_STEP_CFG:.3e} FLOP; "
                       f"the rest is EXTRAPOLATED at the blended rate: {est_s:.0f} s/step",

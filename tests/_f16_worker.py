@@ -14,7 +14,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def rel_l2(a, b):
-    return ((a.float() - b.float()).pow(2).sum().sqrt() / b.float().pow(2).sum().sqrt()).item()
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).pow(2).sum().sqrt() / b.pow(2).sum().sqrt()).item()
 
 
 def main():
@@ -127,6 +128,22 @@ def main():
             num += (got - ref).pow(2).sum().item()
             dsum += ref.pow(2).sum().item()
         res["full_size_step"] = {"rel_l2": (num / dsum) ** 0.5, "finite": bool(torch.isfinite(out).all())}
+    # ---- mixed storage: the first stage and the conditioner store bf16 inside this fp16 process (ops.storage) ----
+    from oracle.make_golden_vae import TINY, images, latents
+    from tests.test_vae_gpu import _decoder
+    from vista_amd.modules.diffusionmodules.model import Encoder
+    gv = torch.load(os.path.join(GOLD, "vae_tiny.pt"))
+    dec, _, _ = _decoder("k311")
+    z = latents(gv["T"], gv["H"], gv["W"], gv["seed_z"]).cuda()
+    out = dec(z, timesteps=gv["T"])
+    enc = Encoder(**TINY)
+    eshapes = {k: tuple(v.shape) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(synth.seeded_state_dict(eshapes, 0), strict=True)
+    mom = enc.cuda()(images(5, 64, 128, 7).cuda())
+    import hashlib
+    res["vae"] = {"decoder_rel_l2": rel_l2(out, gv["out_k311"]), "decoder_dtype": str(out.dtype), "encoder_rel_l2": rel_l2(mom, gv["enc_moments"]),
+                  "act_after": str(ops.ACT), "current_after": _lib.CURRENT, "libs_loaded": sorted(_lib._libs),
+                  "decoder_sha": hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest(), "encoder_sha": hashlib.sha256(mom.cpu().numpy().tobytes()).hexdigest()}
     print("F16_RESULT " + json.dumps(res))
 
 

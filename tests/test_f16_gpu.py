@@ -58,3 +58,26 @@ def test_f16_samplers_vs_reference_golden(f16):
     for name, r in f16["sampler"].items():
         assert r <= 2.4e-3, (name, r)
     assert f16["config1_miniature"] <= 1.8e-3, f16["config1_miniature"]
+
+
+def test_f16_process_runs_the_first_stage_in_bf16_storage(f16):
+    """ops.storage (round 6): inside the fp16 process the VAE decoder / encoder forwards switch to the bf16 library for the duration of the call (the reference
+    runs the first stage without autocast; fp16's exponent is not safe there) -- bitwise what a bf16 process computes, and the fp16 state is back afterwards."""
+    import hashlib
+    import torch
+    from oracle.make_golden_vae import TINY, images, latents
+    from tests.test_vae_gpu import GOLD, _decoder
+    from vista_amd import synth
+    from vista_amd.modules.diffusionmodules.model import Encoder
+    v = f16["vae"]
+    assert v["decoder_dtype"] == "torch.float32" and v["decoder_rel_l2"] < 4e-2 and v["encoder_rel_l2"] < 4e-2, v
+    assert v["act_after"] == "torch.float16" and v["current_after"] == "fp16" and v["libs_loaded"] == ["bf16", "fp16"], v
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"))
+    dec, _, _ = _decoder("k311")
+    out = dec(latents(g["T"], g["H"], g["W"], g["seed_z"]).cuda(), timesteps=g["T"])
+    enc = Encoder(**TINY)
+    shapes = {k: tuple(t.shape) for k, t in enc.state_dict().items()}
+    enc.load_state_dict(synth.seeded_state_dict(shapes, 0), strict=True)
+    mom = enc.cuda()(images(5, 64, 128, 7).cuda())
+    assert hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest() == v["decoder_sha"], "the decoder of an fp16 process differs from a bf16 process's"
+    assert hashlib.sha256(mom.cpu().numpy().tobytes()).hexdigest() == v["encoder_sha"], "the encoder of an fp16 process differs from a bf16 process's"

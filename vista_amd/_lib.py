@@ -9,13 +9,23 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VISTA_HIP_LIB: A/B tooling only (tools/build_rev.sh builds the library of another git revision next to the in-tree one so that two
 # kernel versions can be timed on the SAME box in one call); the product always loads the in-tree build.
-# VISTA_ACT_DTYPE (round 6): the 16-bit storage type of activations and weights for THIS process -- "bf16" (default: libvista_hip.so, the dtype
-# BASELINE config 2 names) or "fp16" (libvista_hip_f16.so, the same kernels built with -DVK_F16=1: the reference's own autocast width,
-# sample_utils.py:301-303; 8x closer to the fp32 oracle at the same speed). One storage type per process: ops.ACT follows it.
+# VISTA_ACT_DTYPE (round 6): the 16-bit storage type of activations and weights of THIS process's denoiser -- "bf16" (default: libvista_hip.so, the
+# dtype BASELINE config 2 names) or "fp16" (libvista_hip_f16.so, the same kernels built with -DVK_F16=1: the reference's own autocast width,
+# sample_utils.py:301-303; 7.6x closer to the fp32 reference at +4 % step time). ops.ACT follows it. The first-stage VAE and the
+# conditioner always store bf16 (the reference runs them without autocast; fp16's 5-bit exponent is not safe there): inside an fp16 process their
+# forwards run under ops.storage(torch.bfloat16), which switches CURRENT -- the library load() hands out -- for the duration of the call.
 ACT_DTYPE = os.environ.get("VISTA_ACT_DTYPE", "bf16").lower()
 if ACT_DTYPE not in ("bf16", "fp16"):
     raise ValueError(f"VISTA_ACT_DTYPE must be 'bf16' or 'fp16', not {ACT_DTYPE!r}")
-LIB_PATH = os.environ.get("VISTA_HIP_LIB") or os.path.join(_HERE, "lib", "libvista_hip_f16.so" if ACT_DTYPE == "fp16" else "libvista_hip.so")
+CURRENT = ACT_DTYPE   # the storage type whose library load() returns: ops.storage() switches it
+_LIB_FILES = {"bf16": "libvista_hip.so", "fp16": "libvista_hip_f16.so"}
+LIB_PATH = os.environ.get("VISTA_HIP_LIB") or os.path.join(_HERE, "lib", _LIB_FILES[ACT_DTYPE])
+
+
+def lib_path(dtype_name):
+    """VISTA_HIP_LIB (A/B tooling) replaces the library of the process's own storage type only."""
+    return LIB_PATH if dtype_name == ACT_DTYPE else os.path.join(_HERE, "lib", _LIB_FILES[dtype_name])
+
 
 _vp = C.c_void_p
 _i32 = C.c_int32
@@ -103,34 +113,36 @@ SIGNATURES = {
     "vk_act_dtype": [],
 }
 
-_lib = None
+_libs = {}
 
 
 class VistaHipError(RuntimeError):
     pass
 
 
-def load():
-    """Open libvista_hip.so and declare prototypes. Raises VistaHipError when the library is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(dtype_name=None):
+    """Open the library of a storage type (default: the current one, CURRENT) and declare prototypes. Raises VistaHipError when it is absent."""
+    name = CURRENT if dtype_name is None else dtype_name
+    lib = _libs.get(name)
+    if lib is not None:
+        return lib
+    path = lib_path(name)
+    if not os.path.exists(path):
         raise VistaHipError(
-            f"{LIB_PATH} not found: build it with `python -m vista_amd.build` (hipcc --offload-arch=gfx950). "
+            f"{path} not found: build it with `python -m vista_amd.build` (hipcc --offload-arch=gfx950). "
             "vista_amd has no CPU / eager fallback.")
-    lib = C.CDLL(LIB_PATH)
-    for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError here = ABI mismatch, surfaced loudly
+    lib = C.CDLL(path)
+    for fname, argtypes in SIGNATURES.items():
+        fn = getattr(lib, fname)  # AttributeError here = ABI mismatch, surfaced loudly
         fn.argtypes = argtypes
         fn.restype = C.c_int
     if lib.vk_abi_version() != ABI_VERSION:
-        raise VistaHipError(f"{LIB_PATH} has ABI version {lib.vk_abi_version()}, this package expects {ABI_VERSION}: rebuild it "
+        raise VistaHipError(f"{path} has ABI version {lib.vk_abi_version()}, this package expects {ABI_VERSION}: rebuild it "
                             "(python -m vista_amd.build --force)")
-    if lib.vk_act_dtype() != (1 if ACT_DTYPE == "fp16" else 0):
-        raise VistaHipError(f"{LIB_PATH} stores {'fp16' if lib.vk_act_dtype() else 'bf16'} but VISTA_ACT_DTYPE={ACT_DTYPE}: "
+    if lib.vk_act_dtype() != (1 if name == "fp16" else 0):
+        raise VistaHipError(f"{path} stores {'fp16' if lib.vk_act_dtype() else 'bf16'} but was opened as the {name} library: "
                             "the library and the host side must agree on the storage type")
-    _lib = lib
+    _libs[name] = lib
     return lib
 
 

@@ -83,6 +83,7 @@ class AutoencoderKLModeOnly(nn.Module):
                 self._pk, self._pk_key = ops.pack_conv3x3(w, b, device=co.weight.device), key
         return self._pk
 
+    @ops.bf16_storage   # (the first stage stores bf16 in every process: ops.storage)
     def encode(self, x, return_reg_log=False, scale=1.0):
         h, H, W = self.encoder.features(x)
         n = h.shape[0]

@@ -208,6 +208,7 @@ class Decoder(nn.Module, Packable):
                 m.invalidate_packed()
         return r
 
+    @ops.bf16_storage   # (the first stage stores bf16 in every process: ops.storage)
     def forward(self, z, **kwargs):
         if z.device.type != "cuda":
             raise ops._lib.VistaHipError("Decoder: latents must be on the MI355X (vista_amd has no CPU path)")
@@ -280,10 +281,12 @@ class Encoder(nn.Module, Packable):
                 m.invalidate_packed()
         return r
 
+    @ops.bf16_storage
     def forward(self, x):
         h, H, W = self.features(x)
         return self.conv_out(h, H, W)
 
+    @ops.bf16_storage
     def features(self, x):
         """Everything up to (and including) norm_out + swish: ((n, H'*W', C) bf16 tokens, H', W'). `conv_out` follows; the mode-only
         autoencoder of the conditioner composes its 1x1 quant_conv into that convolution (models/autoencoder.AutoencoderKLModeOnly)."""

@@ -270,6 +270,7 @@ class FrozenOpenCLIPImageEmbedder(AbstractEmbModel, Packable):
         pooled = ops.layernorm(cls, v.ln_post.weight, v.ln_post.bias, v.ln_post.eps)
         return ops.linear(pooled, pk["proj"], out_f32=True)[:, :g["embed"]]
 
+    @ops.bf16_storage   # (the conditioner stores bf16 in every process: ops.storage)
     def encode_with_vision_transformer(self, img):
         if img.dim() != 4:
             raise NotImplementedError("image crops (5-D input) are not used by Vista's inference configuration")

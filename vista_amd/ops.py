@@ -22,6 +22,46 @@ BF16 = ACT
 F32 = torch.float32
 
 
+class storage:
+    """Context manager: run the enclosed ops with another 16-bit storage type -- `with ops.storage(torch.bfloat16):` switches ops.ACT / ops.BF16 (every
+    function of this file reads them at call time) and the library _lib.load() hands out, and restores both on exit. A no-op when the type is already
+    current (any bf16 process). Used by the first-stage VAE and the conditioner, which store bf16 in every process (the reference runs them without
+    autocast; fp16's exponent range is not safe there), so that an fp16 process (VISTA_ACT_DTYPE=fp16) can run the whole pipeline: denoiser in fp16,
+    decode / encode / CLIP tower in bf16. Weight packs are built under the context that uses them (a module is only ever run under one type).
+    Process-global, not thread-local: do not interleave two storage types from concurrent host threads."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError("ops.storage: torch.bfloat16 or torch.float16")
+        self.dtype, self.name = dtype, ("fp16" if dtype is torch.float16 else "bf16")
+
+    def __enter__(self):
+        global ACT, BF16
+        self.prev = (ACT, _lib.CURRENT)
+        ACT = BF16 = self.dtype
+        _lib.CURRENT = self.name
+        return self
+
+    def __exit__(self, *exc):
+        global ACT, BF16
+        ACT = BF16 = self.prev[0]
+        _lib.CURRENT = self.prev[1]
+        return False
+
+
+def bf16_storage(fn):
+    """Decorator for forwards that always store bf16 (first-stage VAE, conditioner): ops.storage(torch.bfloat16) around the call."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        if ACT is torch.bfloat16:
+            return fn(*a, **k)
+        with storage(torch.bfloat16):
+            return fn(*a, **k)
+    return wrapped
+
+
 def _stream():
     # raw hipStream_t of torch's current stream on the current device; the C-level getters cost ~1 us against ~9 us for
     # torch.cuda.current_stream() (1500 launches per step go through here)
