@@ -87,6 +87,23 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             tm = panel * GM + r % gm;
             tn = r / gm;
         }
+        // TEMPORAL3 (round 6): walk the row tiles FRAME-fastest. Rows are (clip, frame, pixel); a tile of frame t reads the same pixels of frames t - 1, t, t + 1,
+        // so every 128-byte piece of the input is read by three tiles. In row order those three are a whole frame (S / 256 tiles) apart -- about one tile time on
+        // an XCD, during which it streams ~17 MB through its 4 MiB L2 -- and two of the three reads come back from the Infinity Cache / HBM (650-750 ticks of own-DMA
+        // wait per K-step, profiles/r04_gemm_pipe.txt section 3). With the frame as the fast index the tiles of ONE pixel block of consecutive frames run side by
+        // side on one XCD (xcd_remap keeps consecutive logical tiles together) and the neighbours' reads are L2 hits. Only where a frame's rows overflow the L2
+        // (S * Cin * 2 > 3 MB: level 0 of the BASELINE window, 5.9 MB per frame: 0.313 -> 0.302 ms per launch; at level 1 -- 2.9 MB per frame, the row order's
+        // re-reads already hit -- the frame-fastest order measured 4 % SLOWER: profiles/r06_temporal_tile_order.txt), whole pixel blocks (S % 256 == 0), whole
+        // row range; the arithmetic per tile is untouched: bitwise the same output.
+        if constexpr (AMODE == AMODE_TEMPORAL3) {
+            if (p.tile_cfg & 8) return;   // (A/B: VISTA_T3_ORDER=0 keeps the row order)
+            const int nblk = p.S / PBM;
+            if (nblk * PBM == p.S && p.m_begin == 0 && tilesM == (p.M / p.S) * nblk && (long long)p.S * p.Cin * 2 > (3LL << 20)) {
+                const int per_clip = p.T * nblk, clip = tm / per_clip, r = tm - clip * per_clip;
+                const int j = r / p.T, t = r - j * p.T;
+                tm = clip * per_clip + t * nblk + j;
+            }
+        }
     };
 
     // ---- staging assignment: 16-byte chunk lc of tile rows lr + 64 * i; the XOR swizzle lives in the SOURCE chunk index (gemm.hip) ----
@@ -417,6 +434,10 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
     const int tilesN = d->N / PBN, tilesM = (d->m_end - d->m_begin + PBM - 1) / PBM;   // (the caller normalised the row range)
     const int ntiles = tilesM * tilesN;
     VkGemmDesc desc = *d;
+    if constexpr (AMODE == AMODE_TEMPORAL3) {   // VISTA_T3_ORDER=0: the row tile order of rounds 4 / 5 instead of the frame-fastest one (A/B hook; kernel: tile_of)
+        static const bool rows = [] { const char* e = getenv("VISTA_T3_ORDER"); return e && atoi(e) == 0; }();
+        desc.tile_cfg = rows ? (desc.tile_cfg | 8) : (desc.tile_cfg & ~8);
+    }
     const bool nt_a = (AMODE == AMODE_DENSE && tilesN <= 4);   // as gemm.hip's launch_cfg: activation rows that few column tiles re-read are streamed non-temporally
     if constexpr (EPI == EPI_LINEAR) {
         if (ksplit > 1) {   // K slices x tiles; the caller (gemm.hip) runs the finishing pass
