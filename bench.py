@@ -307,6 +307,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay every step's UNet forward from one captured hipGraph (FusedLoop(graph=True)): the DEFAULT on one "
                     "GPU since round 6 (same kernels on the same buffers, bitwise the eager loop's result: tests/test_model_gpu.py::test_hipgraph_*; 165.2 vs 165.4 "
                     "ms per step, host enqueue 0.4 vs 10 ms); the level-0 attention launches of the roofline object are timed on two extra eager steps")
+    ap.add_argument("--one-stream", action="store_true", help="one GPU, graph replay: the step's two guidance halves as ONE forward of 50 images on one stream (the form of "
+                    "rounds 1-5) instead of two concurrent 25-image graphs on two streams (FusedLoop(cfg_streams=True), the default since round 6: -2.4 %)")
     ap.add_argument("--eager", action="store_true", help="one GPU: enqueue every launch from Python each step instead of replaying the captured graph")
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5, NOT the headline: FeedForward GEMMs AND the ResBlock convolutions in fp8 e4m3 (reported dtype says so)")
@@ -396,7 +398,7 @@ def main():
                 tmp.step(i)
             del tmp
         loop = FusedLoop(sampler, fd, x.float().clone(), cond, uc, w["cond_frame"].cuda(), w["cond_mask"].cuda(), True, sig, shard=shard,
-                         graph=graph)
+                         graph=graph, cfg_streams=bool(graph and shard is None and not args.one_stream))
         for i in range(args.warmup):
             loop.step(i)
         torch.cuda.synchronize()
@@ -501,6 +503,8 @@ def main():
                     "weights replicated")},
         "roofline": roofline,
         "hipgraph": bool(args.graph),
+        # the two guidance halves of every step as two concurrent 25-image hipGraphs on two streams (exact: the halves only share the batch axis)
+        "cfg_streams": bool(args.graph and shard is None and not args.one_stream),
         "host_enqueue_ms_idle_stream": None if t_enqueue is None else t_enqueue * 1e3,  # one step enqueued after a sync, outside the timed region
         "step_mfma_frac": (FLOP_PER_STEP_CFG / (ms_per_step * 1e-3) / (MFMA_BF16_PEAK * world)) if full else None,
     }

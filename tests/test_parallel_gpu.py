@@ -243,3 +243,16 @@ def test_two_ranks_over_rccl_match_golden(mode):
     res = _run(_torchrun(2, 29643 if mode == "hybrid" else 29644, os.path.join(ROOT, "tests", "_dist_worker.py"), mode), {"VISTA_DIST_BACKEND": "nccl"})
     assert res["world"] == 2 and res["backend"] == "nccl" and all(r <= 4e-2 for r in res["rel_l2"]) and all(res["cond_frame_exact"])
     assert len(set(res["checksums"])) == 1
+
+
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_single_rank_group_over_rccl_matches_golden(chunks):
+    """The sharded step with every collective issued on a real RCCL process group of ONE rank (a one-GPU box cannot hold two: RCCL
+    refuses duplicate devices). FrameShard.selfcheck and the 3-step CFG sampler run through DistComm(backend "nccl"): the call
+    signatures, dtypes, zero-length splits, asynchronous Work handles (chunks = 2) and the stream ordering between RCCL's stream and
+    the kernels' are the library's own; what stays untested without a second GPU is the transport."""
+    res = _run(_torchrun(1, 29645 + chunks, os.path.join(ROOT, "tests", "_dist_worker.py"), "rccl1"),
+               {"VISTA_DIST_BACKEND": "nccl", "VISTA_A2A_CHUNKS": str(chunks)})
+    assert res["world"] == 1 and res["backend"] == "nccl" and res["a2a_chunks"] == chunks and res["selfcheck_steps"] >= 10
+    assert all(r <= 4e-2 for r in res["rel_l2"]) and all(res["cond_frame_exact"])
+    print(f"[parity] one-rank RCCL group, VISTA_A2A_CHUNKS={chunks}: rel-L2 {res['rel_l2']}, {res['selfcheck_steps']} selfcheck steps")

@@ -133,9 +133,15 @@ class FusedLoop:
     """State of one fused sampling run; `step(i)` is exactly one EulerEDMSampler.sampler_step (sampling.py:78-89):
     mask replace -> CFG-doubled UNet forward -> guider combine -> to_d -> Euler update. bench.py times this."""
 
-    def __init__(self, sampler, fd, xw, cond, uc, cond_frame, maskf, replace, sig, shard=None, graph=None):
+    def __init__(self, sampler, fd, xw, cond, uc, cond_frame, maskf, replace, sig, shard=None, graph=None, cfg_streams=None):
         from .video_model import CIN_PAD
         self.cin_pad = CIN_PAD
+        # cfg_streams (default: env VISTA_CFG_STREAMS, "0"): run the two guidance halves of a step as TWO UNet forwards of n images each
+        # instead of one of 2n -- exact, the halves only meet on the batch axis (guiders.py:27-44) -- and, with graph replay, CONCURRENTLY:
+        # half 0's graph on the launch stream, half 1's on a side stream, each with a split-K workspace of its own. The chip back-fills
+        # one half's ragged last rounds and HBM-bound launches with the other half's work: 159.8 against 163.8 ms per UNet forward pair at
+        # BASELINE config 2, while the same two forwards on one stream take 170.2 (profiles/r06_cfg_streams.txt). Eagerly the halves run one
+        # after the other (bitwise the concurrent replays: same kernels, same buffers). One GPU only: a frame-shard rank keeps one stream.
         # graph: replay the UNet forward of every step from ONE captured hipGraph (the ~800 launches of a step become one host call; the
         # per-step scalars live in the sampler kernels outside it, the noise level enters through a device tensor). Default: env VISTA_HIPGRAPH=1.
         # Off whenever the forward contains collectives (frame-sharded groups): capturing RCCL is left opt-in (VISTA_HIPGRAPH=force).
@@ -172,12 +178,16 @@ class FusedLoop:
             self.y2 = both("vector")[self.half]
             self.mask2 = maskf
         self.cf = loc(cond_frame.float().contiguous()) if replace else None
+        want_cs = os.environ.get("VISTA_CFG_STREAMS", "0") if cfg_streams is None else ("1" if cfg_streams else "0")
+        self._split = want_cs == "1" and shard is None
         # EDM coefficients per step on the host (denoiser_scaling.py:51-59): no device round trip inside the loop
         self.coef = [tuple(float(v) for v in self.den.scaling(torch.tensor(s, dtype=torch.float32))) for s in sig[:-1]]
 
     def _unet(self, net_in, n_ts, c_noise):
         """One UNet forward on the step's input; eager, or the replay of the captured graph (same kernels, same buffers every step)."""
         use = self._graph_mode == "force" or (self._graph_mode == "1" and self.unet_shard is None)
+        if self._split:
+            return self._unet_halves(net_in, c_noise, use)
         if not use:
             ts = torch.full((n_ts,), c_noise, device=self.xw.device)
             return self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.unet_shard)
@@ -189,9 +199,36 @@ class FusedLoop:
         g["graph"].replay()
         return g["out"]
 
-    _WARM_STREAMS = {}   # device -> the one side stream every warm-up forward runs on
+    def _unet_halves(self, net_in, c_noise, graph):
+        """cfg_streams: the step's forward as two forwards of n images (uncond rows [0, n), cond rows [n, 2n)); returns the (2n, S, C) output."""
+        n = self.n
+        half = lambda t, h: t[h * n:(h + 1) * n]  # noqa: E731
+        if not graph:
+            ts = torch.full((n,), c_noise, device=self.xw.device)
+            return torch.cat([self.unet.forward_tokens(half(net_in, h), ts, half(self.ctx2, h), half(self.y2, h), half(self.mask2, h), self.T, self.H, self.W)
+                              for h in (0, 1)])
+        gs = self._graph
+        if gs is None:
+            gs = self._graph = [self._graph_for(half(net_in, h), n, ctx=half(self.ctx2, h), y=half(self.y2, h), mask=half(self.mask2, h), slot=h) for h in (0, 1)]
+        for h in (0, 1):
+            gs[h]["in"].copy_(half(net_in, h))
+            gs[h]["ts"].fill_(c_noise)
+        dev = net_in.device
+        side = FusedLoop._CFG_STREAMS.get(dev.index)
+        if side is None:
+            side = FusedLoop._CFG_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            gs[1]["graph"].replay()
+        gs[0]["graph"].replay()
+        cur.wait_stream(side)
+        return torch.cat([gs[0]["out"], gs[1]["out"]])
 
-    def _graph_for(self, net_in, n_ts):
+    _WARM_STREAMS = {}   # device -> the one side stream every warm-up forward runs on
+    _CFG_STREAMS = {}    # device -> the side stream half 1's graph is replayed on (cfg_streams)
+
+    def _graph_for(self, net_in, n_ts, ctx=None, y=None, mask=None, slot=0):
         """The captured forward for this window geometry. Graphs are cached on the UNet (not per FusedLoop: do_sample builds a FusedLoop per
         sampling round) and keyed by everything that fixes the launch sequence; the conditioning tensors are STATIC buffers of the graph,
         refreshed by copy when another run (re-)uses it. Warm-up and capture run inside ops.graph_workspace() -- one split-K workspace per
@@ -199,12 +236,14 @@ class FusedLoop:
         unet = self.unet
         cache = unet.__dict__.setdefault("_hipgraph_cache", {})
         from .. import attention as _att
+        if ctx is None:
+            ctx, y, mask = self.ctx2, self.y2, self.mask2
         # ... including the module-level switches that decide WHICH kernels forward_tokens launches (bench.py's config-5 side figure and the
         # fp8 tests flip them in-process): a graph captured under other switches must not be replayed
         switches = (tuple(sorted(_att.FP8.items())), _att.FF_FUSED, _att.QKV_SPLIT, _att.Q_LOG2, ops.TILE_CFG, ops.GN_EPI,
                     None if self.unet_shard is None else getattr(self.unet_shard, "a2a_chunks", None))
-        key = (tuple(net_in.shape), n_ts, tuple(self.ctx2.shape), tuple(self.y2.shape), tuple(self.mask2.shape), self.T, self.H, self.W,
-               None if self.unet_shard is None else id(self.unet_shard), str(net_in.device), switches)
+        key = (tuple(net_in.shape), n_ts, tuple(ctx.shape), tuple(y.shape), tuple(mask.shape), self.T, self.H, self.W,
+               None if self.unet_shard is None else id(self.unet_shard), str(net_in.device), switches, slot)
         g = cache.get(key)
         # the captured launches hold raw pointers into the packed weights (owned by the modules' _pk, not by the graph pool): the key covers
         # what Packable itself can see (identity + version counter of every parameter) AND the pack generation, which every
@@ -217,15 +256,15 @@ class FusedLoop:
             if ops.PROFILE_ATTN is not None:
                 raise RuntimeError("ops.PROFILE_ATTN records timing events around attention launches; clear it before capturing a hipGraph")
             dev = net_in.device
-            g = {"in": torch.empty_like(net_in), "ts": torch.empty((n_ts,), device=dev), "ctx": self.ctx2.clone(), "y": self.y2.clone(),
-                 "mask": self.mask2.clone(), "wkey": wkey}
+            g = {"in": torch.empty_like(net_in), "ts": torch.empty((n_ts,), device=dev), "ctx": ctx.clone(), "y": y.clone(),
+                 "mask": mask.clone(), "wkey": wkey}
             g["in"].copy_(net_in)
             g["ts"].fill_(0.0)
             fwd = lambda: unet.forward_tokens(g["in"], g["ts"], g["ctx"], g["y"], g["mask"], self.T, self.H, self.W, shard=self.unet_shard)  # noqa: E731
             side = FusedLoop._WARM_STREAMS.get(dev.index)
             if side is None:
                 side = FusedLoop._WARM_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-            with ops.graph_workspace():
+            with ops.graph_workspace(slot):   # (slot: the two halves of cfg_streams replay at the same time -- a workspace each)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):   # eager warm-up off the capture: weight packs and caches get built here
                     fwd()
@@ -239,9 +278,9 @@ class FusedLoop:
                     g["out"] = fwd()
             cache[key] = g
         else:   # another run of the same geometry: its conditioning goes into the graph's static buffers
-            g["ctx"].copy_(self.ctx2)
-            g["y"].copy_(self.y2)
-            g["mask"].copy_(self.mask2)
+            g["ctx"].copy_(ctx)
+            g["y"].copy_(y)
+            g["mask"].copy_(mask)
         return g
 
     def step(self, i):

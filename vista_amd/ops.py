@@ -244,7 +244,8 @@ class _GraphTLS(threading.local):
 
     def __init__(self):
         self.depth = 0
-        self.ws = {}
+        self.slot = 0    # the workspace slot of the innermost graph_workspace()
+        self.ws = {}     # device (slot 0) or (device, slot) -> workspace
 
 
 _GRAPH_TLS = _GraphTLS()
@@ -252,28 +253,40 @@ _GRAPH_TLS = _GraphTLS()
 
 class graph_workspace:
     """Context manager for hipGraph warm-up + capture (sampling.FusedLoop): every split-K GEMM enqueued inside uses ONE workspace per (thread,
-    device), allocated here -- OUTSIDE any capture, so it belongs to the ordinary caching allocator and not to a graph's private pool -- instead
-    of a fresh 160 MB buffer per (thread, stream). Graph replays run on the launch stream one after the other, so they may share it; eager work
-    on other streams keeps its per-stream buffers."""
+    device, slot), allocated here -- OUTSIDE any capture, so it belongs to the ordinary caching allocator and not to a graph's private pool --
+    instead of a fresh 160 MB buffer per (thread, stream). Graph replays run on the launch stream one after the other, so they may share it; eager
+    work on other streams keeps its per-stream buffers. `slot` > 0: a workspace of its own for a graph that is replayed CONCURRENTLY with the
+    slot-0 graphs on another stream (the two guidance halves of a step, FusedLoop(cfg_streams=True))."""
+
+    def __init__(self, slot=0):
+        self.slot = slot
 
     def __enter__(self):
         dev = torch._C._cuda_getDevice()
-        if SPLITK_WS_BYTES and dev not in _GRAPH_TLS.ws:
+        key = dev if self.slot == 0 else (dev, self.slot)
+        if SPLITK_WS_BYTES and key not in _GRAPH_TLS.ws:
             if torch.cuda.is_current_stream_capturing():
                 raise RuntimeError("ops.graph_workspace must be entered before the capture starts")
-            _GRAPH_TLS.ws[dev] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{dev}")
+            _GRAPH_TLS.ws[key] = torch.empty(SPLITK_WS_BYTES // 4, dtype=F32, device=f"cuda:{dev}")
         _GRAPH_TLS.depth += 1
+        self._outer, _GRAPH_TLS.slot = _GRAPH_TLS.slot, self.slot
         return self
 
     def __exit__(self, *exc):
         _GRAPH_TLS.depth -= 1
+        _GRAPH_TLS.slot = self._outer
         return False
 
 
+def _graph_ws_key():
+    dev, slot = torch._C._cuda_getDevice(), _GRAPH_TLS.slot
+    return dev if slot == 0 else (dev, slot)
+
+
 def graph_workspace_tensor():
-    """The calling thread's graph workspace on the current device (None before the first graph_workspace()): a graph-cache entry holds a reference to
-    it for as long as its graph lives."""
-    return _GRAPH_TLS.ws.get(torch._C._cuda_getDevice())
+    """The calling thread's graph workspace on the current device (inside graph_workspace(slot): that slot's; None before the first
+    graph_workspace()): a graph-cache entry holds a reference to it for as long as its graph lives."""
+    return _GRAPH_TLS.ws.get(_graph_ws_key())
 
 
 def _splitk_workspace(stream):
@@ -282,7 +295,7 @@ def _splitk_workspace(stream):
     concurrently. Held in thread-local storage, so a worker thread's buffers are released when the thread exits. Inside
     graph_workspace() (hipGraph warm-up / capture) the thread's single graph workspace of the device is used instead."""
     if _GRAPH_TLS.depth > 0:
-        return _GRAPH_TLS.ws[torch._C._cuda_getDevice()]
+        return _GRAPH_TLS.ws[_graph_ws_key()]
     key = (torch._C._cuda_getDevice(), stream.value)
     ws = _SPLITK_WS.ws.get(key)
     if ws is None:
