@@ -69,13 +69,15 @@ def main():
         h0["graph"].replay()
         h1["graph"].replay()
 
-    def run_two():
+    def run_two(delay_cycles=0):
         cur = torch.cuda.current_stream()
         sa.wait_stream(cur)
         sb.wait_stream(cur)
         with torch.cuda.stream(sa):
             h0["graph"].replay()
         with torch.cuda.stream(sb):
+            if delay_cycles:
+                torch.cuda._sleep(delay_cycles)   # half 1 starts late: do the halves overlap better out of phase?
             h1["graph"].replay()
         cur.wait_stream(sa)
         cur.wait_stream(sb)
@@ -106,6 +108,8 @@ def main():
     for rnd in range(2):
         print(f"round {rnd}: one N={2 * T} graph {timeit(run_full):8.2f} ms | two N={T} graphs, one stream {timeit(run_serial):8.2f} ms | "
               f"two streams {timeit(run_two):8.2f} ms", flush=True)
+    for us in (100, 300, 1000, 3000):   # torch.cuda._sleep counts ~100 MHz ticks on ROCm builds (wall time is what is printed)
+        print(f"two streams, half 1 delayed by _sleep({us * 100}): {timeit(lambda: run_two(us * 100)):8.2f} ms", flush=True)
 
 
 if __name__ == "__main__":
