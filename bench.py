@@ -306,7 +306,8 @@ def main():
     ap.add_argument("--plumbing-only", action="store_true", help="N > 1: rendezvous + partition/exchange check on the host, no GPU work")
     ap.add_argument("--graph", action="store_true", help="replay every step's UNet forward from one captured hipGraph (FusedLoop(graph=True)): the DEFAULT on one "
                     "GPU since round 6 (same kernels on the same buffers, bitwise the eager loop's result: tests/test_model_gpu.py::test_hipgraph_*; 165.2 vs 165.4 "
-                    "ms per step, host enqueue 0.4 vs 10 ms); the level-0 attention launches of the roofline object are timed on two extra eager steps")
+                    "ms per step, host enqueue 0.4 vs 10 ms); the level-0 attention launches of the roofline object are timed on two extra eager steps. N > 1: "
+                    "refused over RCCL (capturing its collectives hangs on this stack, DESIGN section 6) unless VISTA_HIPGRAPH_RCCL=1")
     ap.add_argument("--one-stream", action="store_true", help="one GPU, graph replay: the step's two guidance halves as ONE forward of 50 images on one stream (the form of "
                     "rounds 1-5) instead of two concurrent 25-image graphs on two streams (FusedLoop(cfg_streams=True), the default since round 6: -2.4 %)")
     ap.add_argument("--eager", action="store_true", help="one GPU: enqueue every launch from Python each step instead of replaying the captured graph")

@@ -47,6 +47,13 @@ def main():
     if mode == "rccl1":
         assert world == 1 and backend == "nccl"
         s.shard = FrameShard(T, DistComm(dist.group.WORLD, name="frames[0..0]"), B=2)
+        s.shard.always_exchange = True   # the UNet forward re-shards through the group although every exchange is a copy to itself
+        calls = {"all_to_all": 0, "all_reduce_sum": 0, "all_gather_list": 0}
+        for name in calls:   # count what actually went through the process group
+            def counted(*a, _f=getattr(s.shard.comm, name), _n=name, **k):
+                calls[_n] += 1
+                return _f(*a, **k)
+            setattr(s.shard.comm, name, counted)
         steps = []
         s.shard.selfcheck("cuda", log=steps.append)
     else:
@@ -61,7 +68,7 @@ def main():
     if rank == 0:
         print(json.dumps({"world": world, "backend": backend, "mode": mode, "t_counts": s.shard.t_counts, "rel_l2": [r[0] for r in gathered],
                           "cond_frame_exact": [r[1] for r in gathered], "checksums": [r[2] for r in gathered],
-                          "selfcheck_steps": len(steps) if mode == "rccl1" else None, "a2a_chunks": s.shard.a2a_chunks}), flush=True)
+                          "selfcheck_steps": len(steps) if mode == "rccl1" else None, "collective_calls": calls if mode == "rccl1" else None, "a2a_chunks": s.shard.a2a_chunks}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
     assert rel <= 4e-2, rel

@@ -254,5 +254,7 @@ def test_single_rank_group_over_rccl_matches_golden(chunks):
     res = _run(_torchrun(1, 29645 + chunks, os.path.join(ROOT, "tests", "_dist_worker.py"), "rccl1"),
                {"VISTA_DIST_BACKEND": "nccl", "VISTA_A2A_CHUNKS": str(chunks)})
     assert res["world"] == 1 and res["backend"] == "nccl" and res["a2a_chunks"] == chunks and res["selfcheck_steps"] >= 10
+    cc = res["collective_calls"]   # selfcheck + 3 steps x one CFG-doubled forward: re-shards, halos and 5-D GroupNorm sums all went through RCCL
+    assert cc["all_to_all"] >= 100 and cc["all_reduce_sum"] >= 30 and cc["all_gather_list"] >= 1, cc
     assert all(r <= 4e-2 for r in res["rel_l2"]) and all(res["cond_frame_exact"])
-    print(f"[parity] one-rank RCCL group, VISTA_A2A_CHUNKS={chunks}: rel-L2 {res['rel_l2']}, {res['selfcheck_steps']} selfcheck steps")
+    print(f"[parity] one-rank RCCL group, VISTA_A2A_CHUNKS={chunks}: rel-L2 {res['rel_l2']}, {res['selfcheck_steps']} selfcheck steps, collectives {cc}")

@@ -11,6 +11,7 @@ including its in-place scaling of the caller's `x` (sampling.py:36). Two executi
               per step, sampling.py:109 and video_model.py:457), the UNet is entered token-major, and the step's
               elementwise work is two kernels (vk_sampler_prepare, vk_sampler_update).
 """
+import os
 from typing import Dict, Union
 
 import torch
@@ -168,7 +169,9 @@ class FusedLoop:
         cu, cc = both("concat")
         self.cu, self.cc = loc(cu.float().contiguous()), loc(cc.float().contiguous())
         self.half = None if shard is None else shard.cfg_half  # CFG x frame hybrid: this rank runs ONE guidance half
-        self.unet_shard = shard if (shard is not None and shard.P > 1) else None  # a 1-rank frame group needs no re-sharding
+        # a 1-rank frame group needs no re-sharding -- unless the shard asks for it (`always_exchange`: the one-rank RCCL test puts every exchange of the
+        # forward through the process group although each is a copy to itself)
+        self.unet_shard = shard if (shard is not None and (shard.P > 1 or getattr(shard, "always_exchange", False))) else None
         if self.half is None:
             self.ctx2 = torch.cat(both("crossattn"), 0)   # full window (replicated on every rank)
             self.y2 = torch.cat(both("vector"), 0)
@@ -188,6 +191,13 @@ class FusedLoop:
         use = self._graph_mode == "force" or (self._graph_mode == "1" and self.unet_shard is None)
         if self._split:
             return self._unet_halves(net_in, c_noise, use)
+        if use and self.unet_shard is not None and getattr(self.unet_shard.comm, "backend", None) == "nccl" \
+                and os.environ.get("VISTA_HIPGRAPH_RCCL", "0") != "1":
+            # measured on the MI355X test boxes (round 6, one-rank nccl group, torch 2.10 + RCCL 2.26.6): capturing the sharded forward hangs -- under
+            # the default capture mode ProcessGroupNCCL's watchdog thread dies with "operation not permitted when stream is capturing", under
+            # "thread_local" the capture never returns (profiles/r06_cfg_streams.txt section 6). Refuse instead of hanging a multi-GPU job.
+            raise RuntimeError("VISTA_HIPGRAPH=force / bench.py --graph with a frame-sharded forward over RCCL: capturing its collectives hangs on this "
+                               "software stack (see DESIGN section 6); run the sharded step eagerly, or set VISTA_HIPGRAPH_RCCL=1 to try anyway")
         if not use:
             ts = torch.full((n_ts,), c_noise, device=self.xw.device)
             return self.unet.forward_tokens(net_in, ts, self.ctx2, self.y2, self.mask2, self.T, self.H, self.W, shard=self.unet_shard)
@@ -274,7 +284,11 @@ class FusedLoop:
                 g["wkey"] = (_att.pack_generation(),) + tuple((id(q), _att.Packable._param_version(q)) for q in unet.parameters())
                 g["ws"] = ops.graph_workspace_tensor()   # the split-K workspace the captured launches point at lives as long as the graph does
                 g["graph"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g["graph"]):
+                # a sharded forward holds collectives: ProcessGroupNCCL's watchdog THREAD polls their events, and under the default "global"
+                # capture mode any HIP call of another thread is an error while this one captures (first run over a real RCCL group, round 6:
+                # "operation not permitted when stream is capturing" from the watchdog, or a hang) -- "thread_local" confines the check to this thread
+                mode = "global" if self.unet_shard is None else "thread_local"
+                with torch.cuda.graph(g["graph"], capture_error_mode=mode):
                     g["out"] = fwd()
             cache[key] = g
         else:   # another run of the same geometry: its conditioning goes into the graph's static buffers
