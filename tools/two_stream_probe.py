@@ -108,6 +108,20 @@ def main():
     for rnd in range(2):
         print(f"round {rnd}: one N={2 * T} graph {timeit(run_full):8.2f} ms | two N={T} graphs, one stream {timeit(run_serial):8.2f} ms | "
               f"two streams {timeit(run_two):8.2f} ms", flush=True)
+    lo, hi = torch.cuda.Stream(priority=0), torch.cuda.Stream(priority=-1)   # does a priority difference between the halves change anything?
+
+    def run_prio():
+        cur = torch.cuda.current_stream()
+        lo.wait_stream(cur)
+        hi.wait_stream(cur)
+        with torch.cuda.stream(hi):
+            h0["graph"].replay()
+        with torch.cuda.stream(lo):
+            h1["graph"].replay()
+        cur.wait_stream(lo)
+        cur.wait_stream(hi)
+    for rnd in range(2):
+        print(f"two streams, equal priority {timeit(run_two):8.2f} ms | half 0 on a high-priority stream {timeit(run_prio):8.2f} ms", flush=True)
     for us in (100, 300, 1000, 3000):   # torch.cuda._sleep counts ~100 MHz ticks on ROCm builds (wall time is what is printed)
         print(f"two streams, half 1 delayed by _sleep({us * 100}): {timeit(lambda: run_two(us * 100)):8.2f} ms", flush=True)
 
