@@ -384,7 +384,9 @@ extern "C" int vk_ff_fused_bf16(const VkGemmDesc* geglu, const VkGemmDesc* out_p
     const int rc = ff_validate(geglu, out_proj);
     if (rc != VK_OK) return rc;
     const int ntiles = (geglu->M + FF_BM - 1) / FF_BM;
-    const int grid = ntiles < 256 ? ntiles : 256;  // persistent: one workgroup per CU (141 KB of LDS) walks the tile list
+    // persistent: one workgroup per CU (141 KB of LDS) walks the tile list. VISTA_FF_WALK=0: one workgroup per tile (A/B hook, as VISTA_GEGLU_WALK)
+    static const bool walk = [] { const char* e = getenv("VISTA_FF_WALK"); return !e || atoi(e) != 0; }();
+    const int grid = (ntiles < 256 || !walk) ? ntiles : 256;
     VkGemmDesc g1 = *geglu, o1 = *out_proj;       // the shared epilogues bound their rows by m_end (ABI v5 row ranges: not offered here, all rows)
     g1.m_begin = o1.m_begin = 0;
     g1.m_end = o1.m_end = geglu->M;

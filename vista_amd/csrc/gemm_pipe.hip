@@ -452,7 +452,9 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
     // per tile -- a workgroup that ends does not wait for its stores, so the next one's first pieces fly while they drain, whereas the tile
     // walk's first barrier (vmcnt(0)) of the next tile waits for every store of the last: measured -7..-10 % on the short-K level-0 / level-1
     // shapes, +-1 % on the deep-K ones (same-box sweep, profiles/r04_gemm_pipe.txt)
-    const int grid = (EPI == EPI_GEGLU && ntiles > 256) ? 256 : ntiles;
+    // VISTA_GEGLU_WALK=0: one workgroup per GEGLU tile as well (A/B hook: do two concurrent half-batch launches interleave better than two tile walks?)
+    static const bool geglu_walk = [] { const char* e = getenv("VISTA_GEGLU_WALK"); return !e || atoi(e) != 0; }();
+    const int grid = (EPI == EPI_GEGLU && ntiles > 256 && geglu_walk) ? 256 : ntiles;
     if constexpr (EPI == EPI_LINEAR && AMODE != AMODE_DENSE) {
         if (desc.gnstat_out) {   // (vk_gemm_pipe_launch checked vk_gemm_pipe_gnstat_ok: N = 320 / 640 / 1280, at most one residual tensor)
             const int nres = (desc.res1 != nullptr) + (desc.res2 != nullptr);
