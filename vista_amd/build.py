@@ -17,6 +17,14 @@ EXTRA_FLAGS = {"ff_fused.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-s
 SOURCES = ["gemm.hip", "gemm_pipe.hip", "gemm_pipe2.hip", "gemm_stream.hip", "gemm_fp8.hip", "ff_fused.hip", "attention.hip", "norm.hip", "elementwise.hip"]
 
 
+# A/B builds: VISTA_BUILD_PIPE4=1 adds the four-wave build of the pipelined GEMM (gemm_pipe4.hip = gemm_pipe.hip with -DPIPE_W4; VISTA_GEMM_PIPE4=1|2|3 then routes
+# launches to it; =2 in VISTA_BUILD_PIPE4 also sets -DPIPE_W4_SPREAD=1). Measured 3-20 % behind the eight-wave kernel (profiles/r06_gemm_pipe4.txt): not in the default library.
+if os.environ.get("VISTA_BUILD_PIPE4", "0") != "0":
+    SOURCES.insert(2, "gemm_pipe4.hip")
+    if os.environ["VISTA_BUILD_PIPE4"] == "2":
+        EXTRA_FLAGS["gemm_pipe4.hip"] = ["-DPIPE_W4_SPREAD=1"]
+
+
 def hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

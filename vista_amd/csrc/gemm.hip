@@ -41,6 +41,9 @@
 // gemm_pipe.hip: the eight-wave pipelined 256x320 variant (tile_cfg 7); fit = 1 when it takes the problem
 extern "C" int vk_gemm_pipe_fit(const VkGemmDesc* d);
 extern "C" int vk_gemm_pipe_launch(const VkGemmDesc* d, void* stream, int ksplit);
+// gemm_pipe4.hip: the same kernel as four waves of 128 x 160 (round-6 experiment, measured 3-20 % behind: profiles/r06_gemm_pipe4.txt). NOT part of the
+// default build (VISTA_BUILD_PIPE4=1 python -m vista_amd.build adds it): a weak reference, resolved only in an A/B library
+extern "C" int vk_gemm_pipe4_launch(const VkGemmDesc* d, void* stream, int ksplit) __attribute__((weak));
 extern "C" int vk_gemm_pipe_gnstat_ok(const VkGemmDesc* d, int ksplit);
 // gemm_pipe2.hip: the four-wave pipelined 128x320 variant, two workgroups per CU (tile_cfg bit 4 / VISTA_GEMM_PIPE2: an A/B option, off by default)
 extern "C" int vk_gemm_pipe2_fit(const VkGemmDesc* d);
@@ -607,8 +610,11 @@ int launch(const VkGemmDesc* d, hipStream_t stream) {
     if constexpr (AMODE != AMODE_CONV3D) {
         // 256x320 as sixteen 32x160 wave tiles (<= 128 VGPRs with single-buffered fragments): +4-11 % over eight 64x160 tiles
         // on the projections and the implicit-GEMM convs (tools/gemm_sweep.py), for the same reason as the 256x256 case below
-        if (t.cfg == 7) {   // eight 64x160 wave tiles, pipelined K-step (gemm_pipe.hip)
-            const int rc = vk_gemm_pipe_launch(d, stream, t.ksplit);
+        if (t.cfg == 7) {   // eight 64x160 wave tiles, pipelined K-step (gemm_pipe.hip); VISTA_GEMM_PIPE4: its four-wave build (gemm_pipe4.hip, A/B hook:
+            // 1 = every launch of this variant, 2 = the convolution loaders only, 3 = the dense loader only)
+            static const int pipe4 = [] { const char* e = getenv("VISTA_GEMM_PIPE4"); return e ? atoi(e) : 0; }();
+            const bool w4 = vk_gemm_pipe4_launch != nullptr && (pipe4 == 1 || (pipe4 == 2 && AMODE != AMODE_DENSE) || (pipe4 == 3 && AMODE == AMODE_DENSE));
+            const int rc = w4 ? vk_gemm_pipe4_launch(d, stream, t.ksplit) : vk_gemm_pipe_launch(d, stream, t.ksplit);
             if (rc != VK_OK || t.ksplit == 1) return rc;
             const long long quads = (long long)d->M * (d->N >> 2);   // the split-K finishing pass, as launch_cfg's
             const int grid = (int)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096);

@@ -532,7 +532,7 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
         if (NRES == 2) rbo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ld_res2 + (uint32_t)wide_off) * 2u;
         oo[fj] = ((uint32_t)mrow[fj] * (uint32_t)p.ldc + (uint32_t)(wide_off - (p.mx8_out ? p.mx8_cols : 0))) * 2u;  // (MX tiles never use it)
     }
-    static_assert(GNC == 0 || (MW == 64 && NW == 160 && NW % GNC == 0 && !MX), "gnstat_out: 64 x 160 wave tiles of whole channel groups");
+    static_assert(GNC == 0 || (MW % 64 == 0 && NW == 160 && NW % GNC == 0 && !MX), "gnstat_out: wave tiles of 64-row blocks x 160 columns of whole channel groups");
     float gs[GN_NG], gq[GN_NG];   // GNC: (sum, sum of squares) of the wave tile's GN_NG channel groups over its 64 rows, this lane's share
     if constexpr (GNC != 0) {
 #pragma unroll
@@ -631,8 +631,16 @@ __device__ __forceinline__ void epilogue_linear_lds_body(const VkGemmDesc& p, f3
             const float so = __shfl_xor(ssum, 32, 64), qo = __shfl_xor(qsum, 32, 64);
             if (lh == 0 && row_ok[fj]) ((float2*)p.rowstat_out)[(size_t)stat_part * p.M + mrow[fj]] = make_float2(ssum + so, qsum + qo);
         }
+        if constexpr (GNC != 0 && FY > 2) {   // 128-row wave tiles (the four-wave build): a slot per 64-row block = per pair of row fragments
+            if ((fj & 1) == 1) {
+                const int mb = m0 + wm * MW + (fj >> 1) * 64;
+                gn_reduce_store<GN_NG>(gs, gq, (float*)p.gnstat_out + (size_t)(mb >> 6) * 64, (n0 + wn * NW) / GNC, l31 | (lh << 5), mb < p.m_end);
+#pragma unroll
+                for (int i = 0; i < GN_NG; ++i) { gs[i] = 0.f; gq[i] = 0.f; }
+            }
+        }
     }
-    if constexpr (GNC != 0) {   // slot = the wave tile's 64-row block (M % 64 == 0: all of its rows are inside the problem, or none)
+    if constexpr (GNC != 0 && FY == 2) {   // slot = the wave tile's 64-row block (M % 64 == 0: all of its rows are inside the problem, or none)
         const int mb = m0 + wm * MW;
         gn_reduce_store<GN_NG>(gs, gq, (float*)p.gnstat_out + (size_t)(mb >> 6) * 64, (n0 + wn * NW) / GNC, l31 | (lh << 5), mb < p.m_end);
     }

@@ -19,23 +19,62 @@
 // Internal entry points, called by gemm.hip's launcher.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "vista_hip.h"
 
 #include "gemm_common.h"
 
+#ifdef PIPE_W4   // the second compile of this file has entry points (and a kernel name in the profiles) of its own
+#define vk_gemm_pipe_fit vk_gemm_pipe4_fit
+#define vk_gemm_pipe_gnstat_ok vk_gemm_pipe4_gnstat_ok
+#define vk_gemm_pipe_launch vk_gemm_pipe4_launch
+#define gemm_pipe_kernel gemm_pipe4_kernel
+#endif
+
 namespace {
 
+// PIPE_W4 (gemm_pipe4.hip compiles this file a second time with it): the SAME kernel as FOUR waves of 128 x 160 -- one wave per SIMD, a 512-register
+// budget (320 accumulator registers, most of them AGPRs), 9 ds_read_b128 per 20 MFMAs instead of 7 per 10 and half the waves at every barrier; the
+// pieces are 32 rows (4 waves x 8 rows), 10 weight + 8 activation pieces per wave and K-step. Round-6 experiment: profiles/r06_gemm_pipe4.txt.
+#ifdef PIPE_W4
+constexpr int PBM = 256, PBN = 320, PNT = 256;
+constexpr int PFX = 5, PFY = 4;
+#else
 constexpr int PBM = 256, PBN = 320, PNT = 512;
-constexpr int PRPP = 64;                       // tile rows per piece (8 waves x 8 rows)
+constexpr int PFX = 5, PFY = 2;                // weight (MFMA row operand) / activation (column operand) fragments per wave
+#endif
+constexpr int PRPP = PNT / 8;                  // tile rows per piece (every wave moves 8 rows of a piece)
 constexpr int PAP = PBM / PRPP, PWP = PBN / PRPP;
 constexpr int PA_BYTES = PBM * 128, PSTAGE = (PBM + PBN) * 128;
-constexpr int PFX = 5, PFY = 2;                // weight (MFMA row operand) / activation (column operand) fragments per wave
+constexpr int PCAP = PNT == 512 ? 256 : 432;   // what the epilogue sizes its residual ring by: 16 registers per accumulator + the ring must fit the ARCH VGPRs (four-wave build: 256 of the 320 accumulator registers are AGPRs, so 432 - 320 - 36 = 76 registers of ring)
+constexpr int APAR0 = 6 * PAP;                 // first bit of the CONV3X3 upsample parities in the validity word
+typedef std::conditional<(8 * PAP > 32), unsigned long long, unsigned>::type amask_t;
 constexpr unsigned P_OOB = 0xffffff00u;        // an offset no resource below reaches (host: every operand < P_LIMIT bytes)
 constexpr unsigned long long P_LIMIT = 0xfffff000ull;
-static_assert(PAP == 4 && PWP == 5, "the piece schedule is written for 5 weight + 4 activation pieces");
+static_assert(PAP + PWP <= PFX * PFY && 8 * PAP <= 64, "the piece schedule issues one piece after each MFMA of the first k-substep");
 
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// The MFMA of the K-loop. Eight-wave build: the builtin. Four-wave build: 320 accumulator registers do not fit the 256 AGPRs, and left to itself the register
+// allocator shuttles accumulators between the two halves of the file inside the loop (1060 v_accvgpr moves and 109 scratch accesses per K-step in the first
+// build) -- so the accumulators of weight fragments 0..3 are PINNED to AGPRs and those of fragment 4 to VGPRs by the operand constraints of an inline-asm MFMA.
+#ifdef PIPE_W4
+#if VK_F16
+#define PIPE_MFMA_OP "v_mfma_f32_32x32x16_f16"
+#else
+#define PIPE_MFMA_OP "v_mfma_f32_32x32x16_bf16"
+#endif
+template <bool AG>
+__device__ __forceinline__ void pipe_mfma(const bf16x8_t& x, const bf16x8_t& y, f32x16_t& c) {
+    if constexpr (AG) asm volatile(PIPE_MFMA_OP " %0, %1, %2, %0" : "+a"(c) : "v"(x), "v"(y));
+    else asm volatile(PIPE_MFMA_OP " %0, %1, %2, %0" : "+v"(c) : "v"(x), "v"(y));
+}
+#define PIPE_MMA(FI, X, Y, C) do { if ((FI) < 4) pipe_mfma<true>(X, Y, C); else pipe_mfma<false>(X, Y, C); } while (0)
+#else
+#define PIPE_MMA(FI, X, Y, C) C = vk_mfma(X, Y, C)
+#endif
 
 #define PIPE_SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -50,7 +89,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // XCD's L2, so that the LDS-DMA of the next iteration finds them there. It is the youngest vector-memory operation at the K-step barrier, whose wait
 // therefore becomes vmcnt(1) + a raw s_barrier (__syncthreads() would wait for it: vmcnt(0)). No arithmetic changes: results are bitwise the same.
 template <int AMODE, int EPI, bool NT_A, bool SPLIT, int GN_CPG = 0, int GN_NRES = 0, bool PF = false>
-__global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, const int ksplit) {
+__global__ __launch_bounds__(PNT, PNT == 512 ? 2 : 1) void gemm_pipe_kernel(const VkGemmDesc p, const int ksplit) {
     static_assert(!PF || AMODE == AMODE_DENSE, "the L2 prefetch is written for the dense loader");
     constexpr int LN_OFF = 2 * PSTAGE, EV_OFF = LN_OFF + PBM * 8;
     constexpr int NTAPS = (AMODE == AMODE_CONV3X3) ? 9 : (AMODE == AMODE_TEMPORAL3) ? 3 : 1;
@@ -117,7 +156,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
     // address state of the tile being staged: a resource per operand, per-lane offsets of the activation row groups, validity bits
     __amdgpu_buffer_rsrc_t rw, ra;
     unsigned voff_a[PAP];   // DENSE / TEMPORAL3: [0] only (the row groups are the uniform stride `apass` apart)
-    unsigned amask = 0;     // CONV3X3: per piece 3 row-valid + 3 column-valid bits (tap (ky, kx) valid = row bit ky & column bit kx); TEMPORAL3: 3 frame bits
+    amask_t amask = 0;      // CONV3X3: per piece 3 row-valid + 3 column-valid bits (tap (ky, kx) valid = row bit ky & column bit kx); TEMPORAL3: 3 frame bits
     auto setup = [&](const int m0, const int n0) __attribute__((always_inline)) {
         rw = __builtin_amdgcn_make_buffer_rsrc((void*)((const uint16_t*)p.Wt + (size_t)n0 * p.K), 0, (int)((unsigned)PBN * (unsigned)p.K * 2u), 0x00020000);
         amask = 0;
@@ -141,7 +180,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
                 // column parities ride in amask's top byte and the lane offset is that of source pixel ((oy >> 1) - 1, (ox >> 1) - 1)
                 const int sh = p.ups - 1;
                 const int ry = sh ? ((y0 + 1) >> 1) - 1 : y0, rx = sh ? ((x0 + 1) >> 1) - 1 : x0;
-                if (sh) amask |= (unsigned)(((y0 + 1) & 1) | (((x0 + 1) & 1) << 1)) << (24 + 2 * i);
+                if (sh) amask |= (amask_t)(((y0 + 1) & 1) | (((x0 + 1) & 1) << 1)) << (APAR0 + 2 * i);
                 // tap (0, 0); wraps for ry / rx = -1, where it is only ever used with a valid tap's offset added
                 voff_a[i] = ((unsigned)((img * p.H + ry) * p.Wd + rx) * (unsigned)p.Cin + (unsigned)lsrc * 8u) * 2u;
                 unsigned mk = 0;
@@ -150,7 +189,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
                     if (m < p.m_end && y0 + t >= 0 && y0 + t < (p.H << sh)) mk |= 1u << t;
                     if (x0 + t >= 0 && x0 + t < (p.Wd << sh)) mk |= 8u << t;
                 }
-                amask |= mk << (6 * i);
+                amask |= (amask_t)mk << (6 * i);
             }
         } else {  // TEMPORAL3: m = (b*T + t)*S + s over [clips*T][S][Cin]; frames outside the window are the conv's zero padding
             ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((unsigned)p.M * (unsigned)p.Cin * 2u), 0x00020000);
@@ -159,11 +198,17 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             for (int i = 0; i < PAP; ++i) {
                 const int m = m0 + lr + PRPP * i;
                 const int t = (m / p.S) % p.T;
-                if (m < p.m_end) amask |= ((t > 0 ? 1u : 0u) | 2u | (t + 1 < p.T ? 4u : 0u)) << (3 * i);
+                if (m < p.m_end) amask |= (amask_t)((t > 0 ? 1u : 0u) | 2u | (t + 1 < p.T ? 4u : 0u)) << (3 * i);
             }
         }
     };
 
+#ifdef PIPE_W4
+#ifndef PIPE_W4_SPREAD
+#define PIPE_W4_SPREAD 0
+#endif
+    constexpr bool w4_spread = PIPE_W4_SPREAD != 0;   // A/B at COMPILE time (-DPIPE_W4_SPREAD=1): two K-loop bodies behind a run-time flag spill 1.2-1.7 KB per lane
+#endif
     const int nk_all = p.K / BK;
     int nk = nk_all;        // K-steps of this workgroup (SPLIT: of its slice, set below)
     int tap = 0, c0b = 0;   // (tap, channel-slab byte offset) of the NEXT K-step to stage (conv loaders: K-step = (slab kt / NTAPS, tap kt % NTAPS))
@@ -187,7 +232,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             const bool ok = ((amask >> (6 * j + ky)) & (amask >> (6 * j + 3 + kx)) & 1u) != 0;
             unsigned v;
             if (p.ups == 2) {   // (kernel-uniform) per-lane tap offset: the source step of a tap depends on the output pixel's parity
-                const unsigned dy = (((amask >> (24 + 2 * j)) & 1u) + (unsigned)(ky + 1)) >> 1, dx = (((amask >> (25 + 2 * j)) & 1u) + (unsigned)(kx + 1)) >> 1;
+                const unsigned dy = ((unsigned)((amask >> (APAR0 + 2 * j)) & 1u) + (unsigned)(ky + 1)) >> 1, dx = ((unsigned)((amask >> (APAR0 + 1 + 2 * j)) & 1u) + (unsigned)(kx + 1)) >> 1;
                 v = voff_a[j] + (dy * (unsigned)p.Wd + dx) * ((unsigned)p.Cin * 2u);
             } else {
                 v = voff_a[j] + (unsigned)((ky * p.Wd + kx) * p.Cin) * 2u;
@@ -225,7 +270,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
 
     // fragment addresses: weights rows wn*160 + 32*f + l31 of sW, activation rows wm*64 + 32*f + l31 of sA, k-substep ks = chunk (2*ks + lh) ^ sw
     const int sw = (l31 >> 1) & 7;
-    const int xrow = PA_BYTES + (wn * 160 + l31) * 128, yrow = (wm * 64 + l31) * 128;
+    const int xrow = PA_BYTES + (wn * 160 + l31) * 128, yrow = (wm * (PFY * 32) + l31) * 128;
     auto load_frags = [&](const int stage, const int ks, bf16x8_t* xf, bf16x8_t* yf) __attribute__((always_inline)) {
         const char* sb = smem + stage * PSTAGE + ((((ks * 2 + lh) ^ sw)) << 4);
 #pragma unroll
@@ -237,7 +282,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
 #pragma unroll
         for (int fi = 0; fi < PFX; ++fi)
 #pragma unroll
-            for (int fj = 0; fj < PFY; ++fj) acc[fi][fj] = vk_mfma(xf[fi], yf[fj], acc[fi][fj]);
+            for (int fj = 0; fj < PFY; ++fj) PIPE_MMA(fi, xf[fi], yf[fj], acc[fi][fj]);
     };
     // the ten MFMAs of one k-substep with the nine pieces of the next K-step, one after each of the first nine MFMAs
     auto mma_dma = [&](const bf16x8_t* xf, const bf16x8_t* yf, const int stage) __attribute__((always_inline)) {
@@ -245,14 +290,34 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         for (int fi = 0; fi < PFX; ++fi)
 #pragma unroll
             for (int fj = 0; fj < PFY; ++fj) {
-                acc[fi][fj] = vk_mfma(xf[fi], yf[fj], acc[fi][fj]);
-                if (fi * 2 + fj < PWP + PAP) {
+                PIPE_MMA(fi, xf[fi], yf[fj], acc[fi][fj]);
+                if (fi * PFY + fj < PWP + PAP) {
                     PIPE_SB();
-                    dma_q(fi * 2 + fj, stage);
+                    dma_q(fi * PFY + fj, stage);
                     PIPE_SB();
                 }
             }
     };
+
+#ifdef PIPE_W4
+    // four-wave build: with one wave per SIMD nothing runs in the shadow of a piece's issue stall, and eighteen pieces in a row cost more than eighteen
+    // spread out (MI355X_MICROARCH: 60 cycles among bare MFMAs, 100-185 inside a phase already carrying pieces) -> one piece after every SECOND MFMA of the
+    // first two k-substeps (q0 = 0 / PWP + PAP - 9 ...): pieces [q0, q0 + n) of the next K-step
+    auto mma_dma_spread = [&](const bf16x8_t* xf, const bf16x8_t* yf, const int stage, const int q0, const int n) __attribute__((always_inline)) {
+#pragma unroll
+        for (int fi = 0; fi < PFX; ++fi)
+#pragma unroll
+            for (int fj = 0; fj < PFY; ++fj) {
+                PIPE_MMA(fi, xf[fi], yf[fj], acc[fi][fj]);
+                const int u = fi * PFY + fj;
+                if ((u & 1) == 0 && (u >> 1) < n) {
+                    PIPE_SB();
+                    dma_q(q0 + (u >> 1), stage);
+                    PIPE_SB();
+                }
+            }
+    };
+#endif
 
     float2* const lnrow = (float2*)(smem + LN_OFF);
     float* const epi_vec = (float*)(smem + EV_OFF);
@@ -317,6 +382,24 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         load_frags(st, 1, xb, yb);
         for (int kt = 0; kt + 1 < nk; ++kt) {
             PIPE_SB();
+#ifdef PIPE_W4
+            if constexpr (w4_spread) {
+                mma_dma_spread(xa, ya, st ^ 1, 0, 9);
+                PIPE_SB();
+                load_frags(st, 2, xa, ya);
+                PIPE_SB();
+                mma_dma_spread(xb, yb, st ^ 1, 9, PWP + PAP - 9);
+                dma_next();
+            } else {
+                mma_dma(xa, ya, st ^ 1);
+                dma_next();
+                PIPE_SB();
+                load_frags(st, 2, xa, ya);
+                PIPE_SB();
+                mma(xb, yb);
+            }
+            PIPE_SB();
+#else
             mma_dma(xa, ya, st ^ 1);
             dma_next();
             prefetch(kt + 2 < nk);   // (kb now names K-step kt + 2)
@@ -325,6 +408,7 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             PIPE_SB();
             mma(xb, yb);
             PIPE_SB();
+#endif
             load_frags(st, 3, xb, yb);
             PIPE_SB();
             mma(xa, ya);
@@ -365,6 +449,9 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
         PIPE_SB();
         mma(xb, yb);
         PIPE_SB();
+#ifdef PIPE_W4   // the hazard recogniser does not see inside the inline-asm MFMAs: their results are read (v_accvgpr_read / VALU) only after the pipe has drained
+        asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+#endif
 #ifdef PIPE_TIMING
         unsigned long long tm_t1;
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_t1) :: "memory");
@@ -401,9 +488,9 @@ __global__ __launch_bounds__(PNT, 2) void gemm_pipe_kernel(const VkGemmDesc p, c
             q.bias = nullptr; q.rowvec = nullptr; q.res1 = nullptr; q.res2 = nullptr;
             q.alpha = 1.f; q.beta = 0.f;
             q.rowvec2 = nullptr; q.ln_stats = nullptr; q.rowstat_out = nullptr; q.act = 0;
-            gemm_epilogue<EPI_LINEAR, true, PFX, PFY, 2, 5>(q, acc, m0, n0, e_wm, e_wn, e_l31, e_lh);
-        } else if constexpr (EPI == EPI_GEGLU) gemm_epilogue_geglu_lds<PFX, PFY, 2, 5, PBN>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, lnp, epi_vec);
-        else gemm_epilogue_linear_lds<PFX, PFY, 2, 5, PBN, 256, GN_CPG, GN_NRES>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0);
+            gemm_epilogue<EPI_LINEAR, true, PFX, PFY, PFY, 5>(q, acc, m0, n0, e_wm, e_wn, e_l31, e_lh);
+        } else if constexpr (EPI == EPI_GEGLU) gemm_epilogue_geglu_lds<PFX, PFY, PFY, 5, PBN>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, lnp, epi_vec);
+        else gemm_epilogue_linear_lds<PFX, PFY, PFY, 5, PBN, PCAP, GN_CPG, GN_NRES>(p, acc, m0, n0, e_wm, e_wn, e_l31, e_lh, tn * 2 + e_wn, lnp, epi_vec, eplan.img0);
 #ifdef PIPE_TIMING
         unsigned long long tm_t2;
         asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tm_t2) :: "memory");
@@ -474,7 +561,7 @@ int pipe_launch(const VkGemmDesc* d, hipStream_t stream, int ksplit) {
         // with the prefetch everywhere); an under-filled launch (the deep levels, every level of a frame-sharded rank) waits out the full memory latency in
         // each K-step and gains 3-33 %. VISTA_GEMM_PF: unset = this rule, 1 = every dense launch, 0 = never (A/B hooks; bitwise the same results).
         static const int pf_env = [] { const char* e = getenv("VISTA_GEMM_PF"); return e ? atoi(e) : -1; }();
-        const bool pf_want = pf_env < 0 ? ntiles <= 256 : pf_env != 0;
+        const bool pf_want = PNT == 512 && (pf_env < 0 ? ntiles <= 256 : pf_env != 0);   // (the prefetch's lane -> row map is written for 512 threads)
         if (pf_want && d->K >= 3 * BK && (d->lda % 64) == 0 && (((size_t)d->A) & 127) == 0) {
             if (nt_a) hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, true, false, 0, 0, true>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
             else hipLaunchKernelGGL((gemm_pipe_kernel<AMODE, EPI, false, false, 0, 0, true>), dim3(grid), dim3(PNT), 0, stream, desc, 1);
