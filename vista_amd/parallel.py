@@ -236,6 +236,9 @@ class FrameShard:
         self.t_off = offsets(self.t_counts)
         self.t_local = self.t_counts[self.rank]
         self._plans = {}
+        # a one-rank group needs no exchange and FusedLoop skips the sharded forward for it -- unless this is set: then every re-shard, halo and statistics
+        # exchange of the forward is issued on the communicator although each is a copy to itself (the one-rank RCCL test on a one-GPU box)
+        self.always_exchange = False
         # VISTA_A2A_CHUNKS = n > 1 (opt-in, default 1): the temporal block runs on n pixel sub-ranges of the rank's slice in turn and each
         # sub-range's way back to the frame layout is its own all-to-all, started asynchronously -- the exchange of sub-range i runs under
         # the compute of sub-range i + 1 (SURVEY 8e "overlap"). Same result bit for bit: the temporal block is pointwise in space.
