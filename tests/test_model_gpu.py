@@ -75,8 +75,12 @@ def _sampler(guider_cfg, steps=3):
                            guider_config=guider_cfg, s_churn=0.0, s_tmin=0.0, s_tmax=999.0, s_noise=1.0, verbose=False, device="cuda")
 
 
-def test_full_size_cfg_step_vs_oracle_checksums():
-    """BASELINE.json config 2 itself, once per test run: ONE CFG-doubled UNet forward (N = 50 images = uncond + cond clip of 25 frames, latent
+@pytest.mark.parametrize("halves", [False, True], ids=["one_forward_of_50", "two_forwards_of_25"])
+def test_full_size_cfg_step_vs_oracle_checksums(halves):
+    """(halves: the step as bench.py runs it since round 6 -- the uncond and the cond clip as two forwards of 25 images, FusedLoop(cfg_streams=True); the
+    concurrent graph replays are bitwise these serial halves, test_cfg_streams_* / tools/two_stream_probe.py. Other tile and split-K choices at the deep
+    levels than the 50-image launch, i.e. another rounding order: measured 1.335e-2 against the one-forward form's 1.287e-2.)
+    BASELINE.json config 2 itself, once per test run: ONE CFG-doubled UNet forward (N = 50 images = uncond + cond clip of 25 frames, latent
     72 x 128, the shipped 1.65 B-parameter network with seeded non-zero weights) on the HIP path against the checksum set the CPU fp32 oracle
     produced for exactly these inputs (tools/make_full_size_checksums.py -> tests/golden/full_size_step_checksums.json: per frame mean, rms
     and 64 values at seeded positions; the oracle itself is pinned to the reference by tests/test_oracle_cpu.py). Stated tolerance, bf16
@@ -92,7 +96,9 @@ def test_full_size_cfg_step_vs_oracle_checksums():
     net, _ = build_unet(320)
     x8, ts, ctx, y, mask = unet_inputs(T, H, W, seed=SEED, sigma=SIGMA)
     with torch.no_grad():
-        out = net(x8.cuda(), timesteps=ts.cuda(), context=ctx.cuda(), y=y.cuda(), cond_mask=mask.cuda(), num_frames=T).float().cpu()
+        parts = [slice(0, T), slice(T, 2 * T)] if halves else [slice(0, 2 * T)]
+        out = torch.cat([net(x8[sl].cuda(), timesteps=ts[sl].cuda(), context=ctx[sl].cuda(), y=y[sl].cuda(), cond_mask=mask[sl].cuda(), num_frames=T).float().cpu()
+                         for sl in parts])
     del net
     torch.cuda.empty_cache()
     assert out.shape == (2 * T, 4, H, W) and torch.isfinite(out).all()
@@ -110,7 +116,7 @@ def test_full_size_cfg_step_vs_oracle_checksums():
         num += (got - ref).pow(2).sum().item()
         den += ref.pow(2).sum().item()
     rel = (num / den) ** 0.5
-    print(f"[full-size CFG step] N=50 72x128 full width: sampled rel-L2 {rel:.3e}; worst frame mean {worst['mean']:.2e} rms, rms {worst['rms']:.2e}, "
+    print(f"[full-size CFG step] N=50 72x128 full width{' as two forwards of 25' if halves else ''}: sampled rel-L2 {rel:.3e}; worst frame mean {worst['mean']:.2e} rms, rms {worst['rms']:.2e}, "
           f"sample {worst['sample']:.2f} of its tolerance")
     assert worst["mean"] <= 1e-2 and worst["rms"] <= 1e-2 and worst["sample"] <= 1.0 and rel <= 1.65e-2, (rel, worst)
 
